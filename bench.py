@@ -1,0 +1,364 @@
+#!/usr/bin/env python3
+"""Headline benchmark: batched rANS float codec, encode + decode, on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bf16|u8|fp16]
+
+Workload (BASELINE.json `metric`: "rANS encode+decode GB/s on 256x1 MiB bf16"):
+256 tensors x 524288 bfloat16 ~ N(0,1) per GPU, probBits
+10, through the C ABI (dgpu_float_compress / dgpu_float_decompress), inputs and
+outputs resident in HBM, temp memory pre-supplied (no allocation in the timed
+region).  One step = one compress pass + one decompress pass over the batch.
+
+value = uncompressed input bytes moved per second over all ranks:
+        N_gpus * 2 * batch_bytes / step_time   (same definition as the
+        reference's benchmark.py:156-157, summed over encode and decode).
+
+For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank codes
+its own 256-tensor shard (weak scaling, no data-path collective; the codec has
+no exchange step); timing is barrier + synchronize on both sides, MAX over
+ranks.  After the timed region the ranks all-gather their compressed sizes
+(RCCL) only to report the aggregate ratio.
+
+The JSON line also carries
+  roofline     -- the dominant kernel's algorithmic bytes / its mean duration,
+                  durations measured with HIP events on the launch stream in a
+                  second, instrumented pass of the same K steps;
+  cpu_baseline -- the CPU oracle (oracle/, kind "port": the reference has no
+                  CPU path) timed on this host's cores on a bounded sample.
+Every run ends with a bit-exact round-trip check.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6290 measured copy
+
+
+def make_workload(kind, batch, seed, device):
+    """Returns (tensors-as-2D tensor, float type or 0, element bytes, prob_bits, description)."""
+    n = 512 * 1024
+    if kind == "bf16":
+        g = torch.Generator(device=device).manual_seed(seed)
+        t = torch.randn((batch, n), generator=g, device=device, dtype=torch.float32).to(torch.bfloat16)
+        return t, 2, 2, 10, f"{batch}x{n} bfloat16 N(0,1), float codec, probBits 10 (BASELINE config 3)"
+    if kind == "fp16":
+        g = torch.Generator(device=device).manual_seed(seed)
+        t = torch.randn((batch, n), generator=g, device=device, dtype=torch.float32)
+        mask = torch.rand((batch, n), generator=g, device=device) < 0.5
+        t = t.masked_fill(mask, 0.0).to(torch.float16)
+        return t, 1, 2, 11, f"{batch}x{n} float16 N(0,1) 50% zeros, float codec, probBits 11 (BASELINE config 4)"
+    if kind == "u8":
+        import refgen
+
+        rows = refgen.zipf_bytes(8, 1 << 20, seed=seed)
+        t = torch.from_numpy(np.tile(rows, (batch // 8, 1))).to(device)
+        return t, 0, 1, 10, f"{batch}x1MiB uint8 Zipf(1.2), raw rANS, probBits 10 (BASELINE config 2)"
+    raise ValueError(kind)
+
+
+class Codec:
+    """Pre-built C-ABI argument arrays so the timed loop is two library calls per step."""
+
+    def __init__(self, dg, data, ft, prob_bits):
+        self.dg, self.lib = dg, dg.lib()
+        self.ft, self.P = ft, prob_bits
+        self.data = data
+        B = data.shape[0]
+        self.B = B
+        dev = data.device
+        self.elems = data.shape[1]
+        self.in_bytes = data.numel() * data.element_size()
+        size_units = self.elems if ft else self.elems * data.element_size()
+        if ft:
+            self.row_cap = int(self.lib.dgpu_float_max_compressed_size(ft, size_units))
+            tmp = max(int(self.lib.dgpu_float_compress_temp_bytes(ft, B, size_units)),
+                      int(self.lib.dgpu_float_decompress_temp_bytes(ft, B, size_units, prob_bits)))
+        else:
+            self.row_cap = int(self.lib.dgpu_ans_max_compressed_size(size_units))
+            tmp = max(int(self.lib.dgpu_ans_encode_temp_bytes(B, size_units)),
+                      int(self.lib.dgpu_ans_decode_temp_bytes(B, size_units, prob_bits)))
+        self.comp = torch.empty((B, self.row_cap), dtype=torch.uint8, device=dev)
+        self.out = torch.empty_like(data)
+        self.sizes = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self.status = torch.zeros((B,), dtype=torch.uint8, device=dev)
+        self.osz = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self.temp = torch.empty((tmp,), dtype=torch.uint8, device=dev)
+        row_in = data.stride(0) * data.element_size()
+        self.in_ptrs = (C.c_void_p * B)(*[data.data_ptr() + i * row_in for i in range(B)])
+        self.comp_ptrs = (C.c_void_p * B)(*[self.comp.data_ptr() + i * self.row_cap for i in range(B)])
+        self.out_ptrs = (C.c_void_p * B)(*[self.out.data_ptr() + i * row_in for i in range(B)])
+        self.in_sizes = (C.c_uint32 * B)(*([size_units] * B))
+        self.stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self.err = C.c_int32(-1)
+
+    def encode(self):
+        L = self.lib
+        tp, tb = C.c_void_p(self.temp.data_ptr()), self.temp.numel()
+        if self.ft:
+            rc = L.dgpu_float_compress(tp, tb, None, self.ft, self.P, 0, self.B, self.in_ptrs, self.in_sizes,
+                                       self.comp_ptrs, C.c_void_p(self.sizes.data_ptr()), self.stream)
+        else:
+            rc = L.dgpu_ans_encode_batch_pointer(tp, tb, None, self.P, 0, self.B, self.in_ptrs, self.in_sizes, None,
+                                                 self.comp_ptrs, C.c_void_p(self.sizes.data_ptr()), self.stream)
+        if rc:
+            raise RuntimeError(L.dgpu_last_error().decode())
+
+    def decode(self):
+        L = self.lib
+        tp, tb = C.c_void_p(self.temp.data_ptr()), self.temp.numel()
+        if self.ft:
+            rc = L.dgpu_float_decompress(tp, tb, None, self.ft, self.P, 0, self.B, self.comp_ptrs, self.out_ptrs,
+                                         self.in_sizes, C.c_void_p(self.status.data_ptr()),
+                                         C.c_void_p(self.osz.data_ptr()), self.stream, C.byref(self.err))
+        else:
+            rc = L.dgpu_ans_decode_batch_pointer(tp, tb, None, self.P, 0, self.B, self.comp_ptrs, self.out_ptrs,
+                                                 self.in_sizes, C.c_void_p(self.status.data_ptr()),
+                                                 C.c_void_p(self.osz.data_ptr()), self.stream, C.byref(self.err))
+        if rc:
+            raise RuntimeError(L.dgpu_last_error().decode())
+
+    def step(self):
+        self.encode()
+        self.decode()
+
+    def verify(self):
+        torch.cuda.synchronize()
+        assert bool(self.status.all().item()), "decode reported failure"
+        a = self.data.view(torch.uint8)
+        b = self.out.view(torch.uint8)
+        assert torch.equal(a, b), "round trip is not bit-exact"
+
+
+def kernel_profile(codec, steps):
+    """Second pass of the same steps with per-kernel HIP events on the launch stream."""
+    L = codec.lib
+    L.dgpu_prof_reset()
+    L.dgpu_prof_enable(1)
+    for _ in range(steps):
+        codec.step()
+    torch.cuda.synchronize()
+    L.dgpu_prof_enable(0)
+    buf = C.create_string_buffer(1 << 16)
+    n = L.dgpu_prof_summary(buf, len(buf))
+    L.dgpu_prof_reset()
+    return json.loads(buf.value.decode()) if n > 0 else {}
+
+
+def algorithmic_bytes(kernel, codec, comp_total):
+    """Algorithmic HBM bytes one launch of `kernel` must move (DESIGN.md section 5,
+    SURVEY.md section 8d): every input byte read once, every output byte written once."""
+    E = codec.B * codec.elems  # elements (float codec) or bytes (raw)
+    if codec.ft:
+        wb = 2 if codec.ft in (1, 2) else 4
+        nc = E * (wb - 1)                      # non-compressed plane bytes
+        ans = comp_total - 16 * codec.B - nc   # compressed exponent archives
+        return {
+            "k_float_split": E * wb + nc + E,  # read words, write non-comp plane + exponent plane
+            "k_ans_encode": E + ans,           # read exponent plane, write archive
+            "k_ans_decode": ans + nc + E * wb, # read archive + non-comp plane, write words
+        }.get(kernel)
+    return {
+        "k_histogram": E,
+        "k_ans_encode": E + comp_total,
+        "k_ans_decode": comp_total + E,
+    }.get(kernel)
+
+
+def cpu_baseline(kind, prob_bits, budget_s=12.0):
+    """Times the CPU oracle (restatement of the reference algorithm; the reference
+    itself has no CPU path) on this host, all cores, on a bounded sample."""
+    import oracle as O
+    import refgen
+
+    cores = os.cpu_count() or 1
+    rows = max(cores, 16)
+    n = 512 * 1024
+    if kind == "u8":
+        data = np.tile(refgen.zipf_bytes(8, 1 << 20), (max(rows // 8, 1), 1))
+        rows = data.shape[0]
+        enc = lambda: O.ans_encode_batch(data, prob_bits, threads=cores)
+        dec = lambda c: O.ans_decode_batch(c, data.shape[1], prob_bits, threads=cores)
+        nbytes = data.size
+    else:
+        ft = O.BFLOAT16 if kind == "bf16" else O.FLOAT16
+        data = refgen.normal_bf16(rows, n) if kind == "bf16" else refgen.sparse_fp16(rows, n)
+        enc = lambda: O.float_compress_batch(ft, data, prob_bits, threads=cores)
+        dec = lambda c: O.float_decompress_batch(ft, c, n, prob_bits, threads=cores)
+        nbytes = data.size * 2
+    comp, _ = enc()  # warm
+    reps, t_enc, t_dec = 0, 0.0, 0.0
+    t_start = time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        comp, _ = enc()
+        t1 = time.perf_counter()
+        out = dec(comp)
+        t2 = time.perf_counter()
+        t_enc += t1 - t0
+        t_dec += t2 - t1
+        reps += 1
+        if time.perf_counter() - t_start > budget_s or reps >= 50:
+            break
+    assert (out == data).all()
+    return {
+        "value": round(2 * nbytes * reps / (t_enc + t_dec) / 1e9, 4),
+        "unit": "GB/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{rows} rows of the same workload x {reps} reps, oracle/ C restatement, "
+                  f"{cores} pthreads (one row per task); encode {nbytes * reps / t_enc / 1e9:.3f} GB/s, "
+                  f"decode {nbytes * reps / t_dec / 1e9:.3f} GB/s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="bf16", choices=["bf16", "u8", "fp16"])
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    import dietgpu_amd as dg
+
+    data, ft, _, prob_bits, desc = make_workload(args.workload, args.batch, 1234 + rank, device)
+    codec = Codec(dg, data, ft, prob_bits)
+
+    def fence():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        codec.step()
+    codec.verify()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        codec.step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    codec.verify()
+
+    # separate encode / decode timings (HIP events on the launch stream)
+    def timed(fn, reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / reps
+
+    enc_ms = timed(codec.encode, args.steps)
+    dec_ms = timed(codec.decode, args.steps)
+
+    sizes = codec.sizes.to(torch.int64)
+    comp_total = int(sizes.sum().item())
+    if distributed:
+        # the only collective: all-gather the per-element compressed sizes (RCCL over xGMI)
+        gathered = [torch.empty_like(codec.sizes) for _ in range(world)]
+        dist.all_gather(gathered, codec.sizes)
+        ratio = float(sum(int(g.to(torch.int64).sum().item()) for g in gathered)) / (codec.in_bytes * world)
+    else:
+        ratio = comp_total / codec.in_bytes
+
+    prof = kernel_profile(codec, args.steps)
+    codec.verify()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * 2 * codec.in_bytes / (elapsed / args.steps) / 1e9
+        kernels = {}
+        for name, rec in prof.items():
+            avg_ms = rec["total_ms"] / max(rec["launches"], 1)
+            ab = algorithmic_bytes(name, codec, comp_total)
+            kernels[name] = {"avg_us": round(avg_ms * 1e3, 2), "launches": rec["launches"]}
+            if ab:
+                kernels[name]["algorithmic_GBps"] = round(ab / (avg_ms * 1e-3) / 1e9, 1)
+        hot = [k for k in kernels if "algorithmic_GBps" in kernels[k]]
+        dom = max(hot, key=lambda k: kernels[k]["avg_us"]) if hot else None
+        roofline = None
+        if dom:
+            ach = kernels[dom]["algorithmic_GBps"]
+            roofline = {
+                "bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                "avg_us": kernels[dom]["avg_us"],
+            }
+        # whole-step figure: algorithmic bytes of encode + decode over the step time
+        E = codec.B * codec.elems
+        if ft:
+            wb = 2 if ft in (1, 2) else 4
+            step_alg = 2 * (E * wb + comp_total)  # encode: read words, write archive; decode: the reverse
+        else:
+            step_alg = 2 * (E + comp_total)
+        out = {
+            "metric": "rans_encode_decode_GBps",
+            "value": round(value, 2),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8" if not ft else "u8 (byte-wise rANS on the split exponent plane of 16-bit words)",
+            "data": "synthetic",
+            "config": {"workload": desc, "per_gpu_batch_bytes": codec.in_bytes,
+                       "api": "C ABI: dgpu_float_compress + dgpu_float_decompress" if ft else
+                              "C ABI: dgpu_ans_encode_batch_pointer + dgpu_ans_decode_batch_pointer",
+                       "sharding": f"{world} ranks x {args.batch} independent tensors, no data-path collective"},
+            "compression_ratio": round(ratio, 4),
+            "encode_GBps": round(codec.in_bytes / (enc_ms * 1e-3) / 1e9, 1),
+            "decode_GBps": round(codec.in_bytes / (dec_ms * 1e-3) / 1e9, 1),
+            "encode_ms": round(enc_ms, 4),
+            "decode_ms": round(dec_ms, 4),
+            "step_algorithmic_GBps": round(step_alg / (elapsed / args.steps) / 1e9, 1),
+            "step_frac_of_hbm_peak": round(step_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS, 4),
+            "roofline": roofline,
+            "kernels": kernels,
+            "round_trip_bit_exact": True,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.workload, prob_bits)
+        print(json.dumps(out), flush=True)
+
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

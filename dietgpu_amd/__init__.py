@@ -1,0 +1,21 @@
+"""dietgpu_amd: MI355X-native batched rANS + float codec behind dietgpu's API.
+
+`dietgpu_amd.ops` mirrors `torch.ops.dietgpu.*`; the product path is
+libdietgpu_amd.so (hand-written HIP for gfx950) reached through the C ABI in
+include/dietgpu_amd.h.  There is no CPU fallback and nothing here imports
+oracle/.
+"""
+from . import ops  # noqa: F401
+from ._lib import DietGpuError, EXPORTED_SYMBOLS, lib  # noqa: F401
+from .ops import (  # noqa: F401
+    compress_data,
+    compress_data_simple,
+    compress_data_split_size,
+    decompress_data,
+    decompress_data_simple,
+    decompress_data_split_size,
+    max_any_compressed_output_size,
+    max_any_compressed_size,
+    max_float_compressed_output_size,
+    max_float_compressed_size,
+)

@@ -1,0 +1,36 @@
+"""Builds libdietgpu_amd.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree."""
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libdietgpu_amd.so")
+
+_SOURCES = ["capi.hip"]
+_DEPS = ["format.h", "kernels_stats.h", "kernels_encode.h", "kernels_decode.h", "kernels_float.h",
+         "capi.hip", os.path.join("..", "..", "include", "dietgpu_amd.h")]
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in _DEPS)
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in _SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build(force=True, verbose=True)

@@ -1,0 +1,1039 @@
+// Host side of the C ABI (include/dietgpu_amd.h): argument checking, temp
+// memory carving, one pinned-memory parameter upload per call, and the kernel
+// launch sequences.  Everything is enqueued on the caller's stream; the only
+// host synchronisation is checksum verification on decode (as upstream,
+// GpuANSDecode.cuh:557-591) and the overflow-allocation fallback.
+#include "../../include/dietgpu_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "format.h"
+#include "kernels_decode.h"
+#include "kernels_encode.h"
+#include "kernels_float.h"
+#include "kernels_stats.h"
+
+using namespace dgpu;
+
+namespace {
+
+thread_local std::string g_lastError;
+
+int fail(int code, const std::string& msg) {
+  g_lastError = msg;
+  return code;
+}
+
+#define DGPU_HIP(expr)                                                              \
+  do {                                                                              \
+    hipError_t e_ = (expr);                                                         \
+    if (e_ != hipSuccess) {                                                         \
+      return fail(DGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    }                                                                               \
+  } while (0)
+
+#define DGPU_REQUIRE(cond, msg)                                      \
+  do {                                                               \
+    if (!(cond)) return fail(DGPU_ERR_INVALID_ARGUMENT, (msg));      \
+  } while (0)
+
+constexpr size_t kTempAlign = 256;  // kSDMAlignment, StackDeviceMemory.h:22
+
+size_t alignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------
+// Optional per-kernel timing with HIP events on the launch stream (used by
+// bench.py for the roofline figure; off by default, zero cost when off).
+struct ProfSpan {
+  const char* name;
+  hipEvent_t start, stop;
+};
+struct ProfState {
+  std::mutex mu;
+  bool enabled = false;
+  std::vector<ProfSpan> open;
+  std::map<std::string, std::pair<uint64_t, double>> acc;  // name -> (launches, total ms)
+};
+ProfState& prof() {
+  static ProfState* p = new ProfState();
+  return *p;
+}
+
+class KernelTimer {
+ public:
+  KernelTimer(const char* name, hipStream_t stream) : stream_(stream) {
+    ProfState& p = prof();
+    if (!p.enabled) return;
+    span_.name = name;
+    if (hipEventCreate(&span_.start) != hipSuccess || hipEventCreate(&span_.stop) != hipSuccess) return;
+    (void)hipEventRecord(span_.start, stream_);
+    active_ = true;
+  }
+  ~KernelTimer() {
+    if (!active_) return;
+    (void)hipEventRecord(span_.stop, stream_);
+    ProfState& p = prof();
+    std::lock_guard<std::mutex> g(p.mu);
+    p.open.push_back(span_);
+  }
+
+ private:
+  hipStream_t stream_;
+  ProfSpan span_{};
+  bool active_ = false;
+};
+
+#define DGPU_LAUNCH(name, stream, ...)   \
+  do {                                   \
+    KernelTimer kt_(name, stream);       \
+    hipLaunchKernelGGL(__VA_ARGS__);     \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// Temp memory: bump allocation out of the caller's region; if it does not fit,
+// fall back to hipMalloc with a warning (StackDeviceMemory.cpp:119-139).
+class TempArena {
+ public:
+  TempArena(void* base, size_t bytes, hipStream_t stream)
+      : base_((uint8_t*)base), bytes_(base ? bytes : 0), stream_(stream) {
+    // honour the 256-byte granularity even if the caller's pointer is odd
+    size_t mis = ((uintptr_t)base_) % kTempAlign;
+    if (base_ && mis) {
+      size_t skip = kTempAlign - mis;
+      if (skip >= bytes_) {
+        base_ = nullptr;
+        bytes_ = 0;
+      } else {
+        base_ += skip;
+        bytes_ -= skip;
+      }
+    }
+  }
+  ~TempArena() { release(); }
+
+  template <typename T>
+  T* alloc(size_t count, hipError_t* err) {
+    size_t need = std::max(alignUp(count * sizeof(T), kTempAlign), kTempAlign);
+    requested_ += need;
+    if (head_ + need <= bytes_) {
+      T* p = (T*)(base_ + head_);
+      head_ += need;
+      return p;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, need);
+    if (e != hipSuccess) {
+      *err = e;
+      return nullptr;
+    }
+    // no warning when the caller chose to pass no temp memory at all
+    if (!warned_ && bytes_ > 0) {
+      fprintf(stderr,
+              "dietgpu_amd: WARNING: temp memory too small (%zu bytes given, > %zu needed); "
+              "falling back to hipMalloc, which synchronises\n",
+              bytes_, requested_);
+      warned_ = true;
+    }
+    overflow_.push_back(p);
+    return (T*)p;
+  }
+
+  size_t requested() const { return requested_; }
+
+  void release() {
+    if (!overflow_.empty()) {
+      (void)hipStreamSynchronize(stream_);
+      for (void* p : overflow_) (void)hipFree(p);
+      overflow_.clear();
+    }
+  }
+
+ private:
+  uint8_t* base_;
+  size_t bytes_;
+  hipStream_t stream_;
+  size_t head_ = 0;
+  size_t requested_ = 0;
+  bool warned_ = false;
+  std::vector<void*> overflow_;
+};
+
+#define DGPU_ALLOC(var, T, arena, count)                                     \
+  T* var = nullptr;                                                          \
+  do {                                                                       \
+    hipError_t e_ = hipSuccess;                                              \
+    var = (arena).alloc<T>((count), &e_);                                    \
+    if (!var) return fail(DGPU_ERR_HIP, std::string("temp alloc: ") + hipGetErrorString(e_)); \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// Host->device parameter upload (pointer / size arrays) through a small ring of
+// pinned buffers, so the copy is a true async DMA and never forces the host to
+// wait for earlier work on the stream.  A slot is reused only after the copy
+// that last read it has completed (event-guarded).
+class ParamStager {
+ public:
+  struct Slot {
+    void* host = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+  };
+
+  // Returns a pinned host buffer of at least `bytes`.
+  hipError_t acquire(size_t bytes, Slot** out) {
+    std::lock_guard<std::mutex> g(mu_);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    Ring& r = rings_[dev];
+    Slot& s = r.slots[r.next];
+    r.next = (r.next + 1) % kSlots;
+    if (s.pending) {
+      e = hipEventSynchronize(s.ev);
+      if (e != hipSuccess) return e;
+      s.pending = false;
+    }
+    if (s.cap < bytes) {
+      if (s.host) (void)hipHostFree(s.host);
+      s.host = nullptr;
+      s.cap = 0;
+      size_t cap = std::max<size_t>(alignUp(bytes, 4096), 16384);
+      e = hipHostMalloc(&s.host, cap, hipHostMallocDefault);
+      if (e != hipSuccess) return e;
+      s.cap = cap;
+    }
+    if (!s.ev) {
+      e = hipEventCreateWithFlags(&s.ev, hipEventDisableTiming);
+      if (e != hipSuccess) return e;
+    }
+    *out = &s;
+    return hipSuccess;
+  }
+
+  hipError_t upload(Slot* s, void* dst_dev, size_t bytes, hipStream_t stream) {
+    hipError_t e = hipMemcpyAsync(dst_dev, s->host, bytes, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+    e = hipEventRecord(s->ev, stream);
+    if (e != hipSuccess) return e;
+    s->pending = true;
+    return hipSuccess;
+  }
+
+ private:
+  static constexpr int kSlots = 16;
+  struct Ring {
+    Slot slots[kSlots];
+    int next = 0;
+  };
+  std::mutex mu_;
+  std::map<int, Ring> rings_;
+};
+
+ParamStager& stager() {
+  static ParamStager* s = new ParamStager();  // intentionally leaked: no teardown-order issues
+  return *s;
+}
+
+BatchView viewStride(const void* base, uint64_t stride, uint32_t uniformSize) {
+  BatchView v;
+  v.ptrs = nullptr;
+  v.base = (uint64_t)(uintptr_t)base;
+  v.stride = stride;
+  v.sizes = nullptr;
+  v.uniformSize = uniformSize;
+  return v;
+}
+
+BatchView viewPointers(const uint64_t* ptrs_dev, const uint32_t* sizes_dev, uint32_t uniformSize) {
+  BatchView v;
+  v.ptrs = ptrs_dev;
+  v.base = 0;
+  v.stride = 0;
+  v.sizes = sizes_dev;
+  v.uniformSize = uniformSize;
+  return v;
+}
+
+uint32_t gridX(uint32_t maxBytes, uint32_t bytesPerBlock, uint32_t cap) {
+  uint32_t x = divUp(std::max(maxBytes, 1u), bytesPerBlock);
+  return std::max(1u, std::min(x, cap));
+}
+
+bool validProbBits(int p) { return p == 9 || p == 10 || p == 11; }
+bool validFloatType(uint32_t ft) { return ft == kFloat16 || ft == kBFloat16 || ft == kFloat32; }
+
+uint32_t maxCompressedSizeHost(uint32_t bytes) {
+  // getMaxCompressedSize, GpuANSEncode.cu:13-25 (block SIZE passed as block COUNT [sic])
+  uint32_t blocks = divUp(bytes, kBlockSize);
+  size_t raw = ansOverhead(kBlockSize);
+  raw += (size_t)roundUp(kBlockSize + kBlockSize / 4, 16) * blocks;
+  raw = alignUp(raw, 16);
+  return (uint32_t)raw;
+}
+
+// Device batch description assembled by each entry point.
+struct DeviceBatch {
+  BatchView in;
+  BatchView out;
+  uint32_t maxSize = 0;
+};
+
+// Layout of the packed parameter block: [in ptrs][out ptrs][sizes]
+struct HostParams {
+  std::vector<uint64_t> inPtrs, outPtrs;
+  std::vector<uint32_t> sizes;
+};
+
+int uploadParams(
+    TempArena& arena, hipStream_t stream, uint32_t B, const HostParams& hp,
+    const uint64_t** inPtrs_dev, const uint64_t** outPtrs_dev, const uint32_t** sizes_dev) {
+  const size_t nIn = hp.inPtrs.size(), nOut = hp.outPtrs.size(), nSz = hp.sizes.size();
+  const size_t bytes = (nIn + nOut) * 8 + alignUp(nSz * 4, 8);
+  if (bytes == 0) return DGPU_OK;
+  DGPU_ALLOC(dev, uint8_t, arena, bytes);
+  ParamStager::Slot* slot = nullptr;
+  DGPU_HIP(stager().acquire(bytes, &slot));
+  uint8_t* h = (uint8_t*)slot->host;
+  if (nIn) memcpy(h, hp.inPtrs.data(), nIn * 8);
+  if (nOut) memcpy(h + nIn * 8, hp.outPtrs.data(), nOut * 8);
+  if (nSz) memcpy(h + (nIn + nOut) * 8, hp.sizes.data(), nSz * 4);
+  DGPU_HIP(stager().upload(slot, dev, bytes, stream));
+  *inPtrs_dev = nIn ? (const uint64_t*)dev : nullptr;
+  *outPtrs_dev = nOut ? (const uint64_t*)(dev + nIn * 8) : nullptr;
+  *sizes_dev = nSz ? (const uint32_t*)(dev + (nIn + nOut) * 8) : nullptr;
+  (void)B;
+  return DGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Launch sequences
+// ---------------------------------------------------------------------------
+
+template <int P>
+int launchEncodeP(const EncodeArgs& a, uint32_t tickets, hipStream_t stream) {
+  DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P>), dim3(tickets), dim3(256), encLdsBytes(P), stream, a);
+  DGPU_HIP(hipGetLastError());
+  return DGPU_OK;
+}
+
+int launchEncode(int P, const EncodeArgs& a, uint32_t tickets, hipStream_t stream) {
+  switch (P) {
+    case 9: return launchEncodeP<9>(a, tickets, stream);
+    case 10: return launchEncodeP<10>(a, tickets, stream);
+    default: return launchEncodeP<11>(a, tickets, stream);
+  }
+}
+
+// Shared tail of every encode entry point: [checksum] -> [histogram] ->
+// normalise -> encode.  `symbols` is the byte plane that is entropy coded.
+//   floatType == 0: symbols == the caller's input, archive == ANS archive.
+//   floatType != 0: symbols == exponent plane in temp memory (already filled
+//     by k_float_split together with `hist`), archive == float archive.
+int encodeCommon(
+    TempArena& arena, hipStream_t stream, int P, bool ansChecksum, uint32_t B,
+    const BatchView& symbols, const BatchView& sizes, const BatchView& archives,
+    uint32_t floatType, uint32_t maxSize, const uint32_t* hist_dev /*may be null*/,
+    uint32_t* zeroRegion, size_t zeroWords, uint32_t* histTemp, uint32_t* checksumTemp,
+    uint64_t* tileDesc, uint32_t* ticket, uint32_t maxTiles, bool zeroAlreadyDone,
+    uint32_t* outSize_dev) {
+  if (!zeroAlreadyDone) {
+    DGPU_HIP(hipMemsetAsync(zeroRegion, 0, zeroWords * 4, stream));
+  }
+  if (ansChecksum) {
+    dim3 grid(gridX(maxSize, 64 * 1024, 64), B);
+    DGPU_LAUNCH("k_checksum", stream, k_checksum, grid, dim3(256), 0, stream, symbols, (const uint32_t*)nullptr, checksumTemp);
+    DGPU_HIP(hipGetLastError());
+  }
+  if (!hist_dev) {
+    dim3 grid(gridX(maxSize, 32 * 1024, 64), B);
+    DGPU_LAUNCH("k_histogram", stream, k_histogram, grid, dim3(256), 0, stream, symbols, histTemp);
+    DGPU_HIP(hipGetLastError());
+    hist_dev = histTemp;
+  }
+  DGPU_ALLOC(table, uint4, arena, (size_t)B * kNumSymbols);
+  {
+    NormalizeArgs n;
+    n.sizes = sizes;
+    n.hist = hist_dev;
+    n.probBits = P;
+    n.encTable = table;
+    n.refTable = nullptr;
+    n.out = archives;
+    n.writeHeader = 1;
+    n.floatType = floatType;
+    n.useChecksum = ansChecksum ? 1 : 0;
+    n.checksum = ansChecksum ? checksumTemp : nullptr;
+    n.outSize = outSize_dev;
+    DGPU_LAUNCH("k_normalize", stream, k_normalize, dim3(B), dim3(256), 0, stream, n);
+    DGPU_HIP(hipGetLastError());
+  }
+  if (maxTiles > 0) {
+    EncodeArgs e;
+    e.in = symbols;
+    e.out = archives;
+    e.sizes = sizes;
+    e.floatType = floatType;
+    e.encTable = table;
+    e.maxTiles = maxTiles;
+    e.tileDesc = tileDesc;
+    e.ticket = ticket;
+    e.outSize = outSize_dev;
+    int rc = launchEncode(P, e, B * maxTiles, stream);
+    if (rc) return rc;
+  }
+  return DGPU_OK;
+}
+
+uint32_t tilesFor(uint32_t maxSize) { return divUp(divUp(maxSize, kBlockSize), kBlocksPerTile); }
+
+// One region zeroed by a single memset per encode call (u32 words):
+//   [hist B*256 (optional)][checksum B (+pad to even)][ticket, pad][tileDesc B*maxTiles u64]
+struct ZeroLayout {
+  size_t checksumAt, ticketAt, descAt, words;
+  ZeroLayout(size_t histWords, uint32_t B, uint32_t maxTiles) {
+    checksumAt = histWords;
+    ticketAt = checksumAt + roundUp(B, 2u);
+    descAt = ticketAt + 2;
+    words = descAt + 2 * (size_t)B * maxTiles;
+  }
+};
+
+int ansEncodeImpl(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, int P, int useChecksum, uint32_t B,
+    const HostParams* hp /*null => stride views below*/, const BatchView* strideIn,
+    const BatchView* strideOut, uint32_t maxSize, const uint32_t* histogram_dev,
+    uint32_t* outSize_dev, hipStream_t stream) {
+  DGPU_REQUIRE(validProbBits(P), "probBits must be 9, 10 or 11");
+  DGPU_REQUIRE(B <= 65535u, "numInBatch must be <= 65535");
+  if (tempUsed) *tempUsed = 0;
+  if (B == 0) return DGPU_OK;
+
+  TempArena arena(temp_dev, tempBytes, stream);
+  BatchView in, out;
+  if (hp) {
+    const uint64_t *inP = nullptr, *outP = nullptr;
+    const uint32_t* sz = nullptr;
+    int rc = uploadParams(arena, stream, B, *hp, &inP, &outP, &sz);
+    if (rc) return rc;
+    in = viewPointers(inP, sz, 0);
+    out = viewPointers(outP, nullptr, 0);
+  } else {
+    in = *strideIn;
+    out = *strideOut;
+  }
+
+  const uint32_t maxTiles = tilesFor(maxSize);
+  const ZeroLayout zl(histogram_dev ? 0 : (size_t)B * kNumSymbols, B, maxTiles);
+  DGPU_ALLOC(zero, uint32_t, arena, zl.words);
+  const size_t zeroWords = zl.words;
+  uint32_t* histTemp = zero;
+  uint32_t* checksumTemp = zero + zl.checksumAt;
+  uint32_t* ticket = zero + zl.ticketAt;
+  uint64_t* tileDesc = (uint64_t*)(zero + zl.descAt);
+
+  int rc = encodeCommon(
+      arena, stream, P, useChecksum != 0, B, in, in, out, 0, maxSize, histogram_dev, zero,
+      zeroWords, histTemp, checksumTemp, tileDesc, ticket, maxTiles, false, outSize_dev);
+  if (tempUsed) *tempUsed = arena.requested();
+  return rc;
+}
+
+template <uint32_t FT>
+void launchSplitFT(const SplitArgs& a, dim3 grid, hipStream_t stream) {
+  DGPU_LAUNCH("k_float_split", stream, (k_float_split<FT>), grid, dim3(256), 0, stream, a);
+}
+
+int floatCompressImpl(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, uint32_t ft, int P, int useChecksum,
+    uint32_t B, const HostParams& hp, uint32_t maxSize, uint32_t* outSize_dev,
+    hipStream_t stream) {
+  DGPU_REQUIRE(validProbBits(P), "probBits must be 9, 10 or 11");
+  DGPU_REQUIRE(validFloatType(ft), "floatType must be float16, bfloat16 or float32");
+  DGPU_REQUIRE(B <= 65535u, "numInBatch must be <= 65535");
+  if (tempUsed) *tempUsed = 0;
+  if (B == 0) return DGPU_OK;
+
+  TempArena arena(temp_dev, tempBytes, stream);
+  const uint64_t *inP = nullptr, *outP = nullptr;
+  const uint32_t* sz = nullptr;
+  int rc = uploadParams(arena, stream, B, hp, &inP, &outP, &sz);
+  if (rc) return rc;
+  BatchView in = viewPointers(inP, sz, 0);
+  BatchView out = viewPointers(outP, nullptr, 0);
+
+  const uint32_t maxTiles = tilesFor(maxSize);
+  const ZeroLayout zl((size_t)B * kNumSymbols, B, maxTiles);
+  DGPU_ALLOC(zero, uint32_t, arena, zl.words);
+  const size_t zeroWords = zl.words;
+  uint32_t* histTemp = zero;
+  uint32_t* checksumTemp = zero + zl.checksumAt;
+  uint32_t* ticket = zero + zl.ticketAt;
+  uint64_t* tileDesc = (uint64_t*)(zero + zl.descAt);
+  DGPU_HIP(hipMemsetAsync(zero, 0, zeroWords * 4, stream));
+
+  // exponent plane, rows 16-byte aligned (GpuFloatCompress.cuh:470-474)
+  const uint32_t compStride = roundUp(std::max(maxSize, 1u), 16u);
+  DGPU_ALLOC(comp, uint8_t, arena, (size_t)B * compStride);
+
+  if (useChecksum) {
+    // Quirk kept from the reference: size in float WORDS consumed as BYTES
+    dim3 grid(gridX(maxSize, 64 * 1024, 64), B);
+    DGPU_LAUNCH("k_checksum", stream, k_checksum, grid, dim3(256), 0, stream, in, (const uint32_t*)nullptr, checksumTemp);
+    DGPU_HIP(hipGetLastError());
+  }
+  {
+    SplitArgs s;
+    s.in = in;
+    s.out = out;
+    s.compOut = comp;
+    s.compStride = compStride;
+    s.useChecksum = useChecksum ? 1 : 0;
+    s.checksum = useChecksum ? checksumTemp : nullptr;
+    s.hist = histTemp;
+    dim3 grid(gridX(maxSize * floatWordBytes(ft), 32 * 1024, 256), B);
+    if (ft == kFloat16) launchSplitFT<kFloat16>(s, grid, stream);
+    else if (ft == kBFloat16) launchSplitFT<kBFloat16>(s, grid, stream);
+    else launchSplitFT<kFloat32>(s, grid, stream);
+    DGPU_HIP(hipGetLastError());
+  }
+  BatchView symbols = viewStride(comp, compStride, 0);
+  symbols.sizes = sz;
+  rc = encodeCommon(
+      arena, stream, P, false, B, symbols, in, out, ft, maxSize, histTemp, zero, zeroWords,
+      histTemp, checksumTemp, tileDesc, ticket, maxTiles, true, outSize_dev);
+  if (tempUsed) *tempUsed = arena.requested();
+  return rc;
+}
+
+template <int P, uint32_t FT>
+int launchDecodePF(const DecodeArgs& a, dim3 grid, hipStream_t stream) {
+  DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode<P, FT>), grid, dim3(256), (4u << P) + kBlocksPerTile * kBlockSize, stream, a);
+  DGPU_HIP(hipGetLastError());
+  return DGPU_OK;
+}
+
+template <uint32_t FT>
+int launchDecodeF(int P, const DecodeArgs& a, dim3 grid, hipStream_t stream) {
+  switch (P) {
+    case 9: return launchDecodePF<9, FT>(a, grid, stream);
+    case 10: return launchDecodePF<10, FT>(a, grid, stream);
+    default: return launchDecodePF<11, FT>(a, grid, stream);
+  }
+}
+
+int decodeImpl(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, uint32_t ft, int P, int useChecksum,
+    uint32_t B, const HostParams* hp, const BatchView* strideIn, const BatchView* strideOut,
+    uint32_t maxCapacity, uint8_t* outSuccess_dev, uint32_t* outSize_dev, hipStream_t stream,
+    int32_t* errBatch) {
+  DGPU_REQUIRE(validProbBits(P), "probBits must be 9, 10 or 11");
+  DGPU_REQUIRE(ft == 0 || validFloatType(ft), "bad floatType");
+  DGPU_REQUIRE(B <= 65535u, "numInBatch must be <= 65535");
+  if (tempUsed) *tempUsed = 0;
+  if (errBatch) *errBatch = -1;
+  if (B == 0) return DGPU_OK;
+
+  TempArena arena(temp_dev, tempBytes, stream);
+  BatchView in, out;
+  if (hp) {
+    const uint64_t *inP = nullptr, *outP = nullptr;
+    const uint32_t* cap = nullptr;
+    int rc = uploadParams(arena, stream, B, *hp, &inP, &outP, &cap);
+    if (rc) return rc;
+    in = viewPointers(inP, nullptr, 0);
+    out = viewPointers(outP, cap, 0);
+  } else {
+    in = *strideIn;
+    out = *strideOut;
+  }
+
+  DGPU_ALLOC(lut, uint32_t, arena, (size_t)B << P);
+  DGPU_LAUNCH("k_decode_table", stream, k_decode_table, dim3(B), dim3(256), 0, stream, in, ft, P, lut);
+  DGPU_HIP(hipGetLastError());
+
+  uint32_t* sizesForChecksum = outSize_dev;
+  uint8_t* successForChecksum = outSuccess_dev;
+  if (useChecksum) {
+    if (!sizesForChecksum) {
+      DGPU_ALLOC(s, uint32_t, arena, B);
+      sizesForChecksum = s;
+    }
+    if (!successForChecksum) {
+      DGPU_ALLOC(s, uint8_t, arena, B);
+      successForChecksum = s;
+    }
+  }
+
+  const uint32_t maxTiles = std::max(1u, tilesFor(maxCapacity));
+  {
+    DecodeArgs d;
+    d.in = in;
+    d.out = out;
+    d.floatType = ft;
+    d.lut = lut;
+    d.outSuccess = useChecksum ? successForChecksum : outSuccess_dev;
+    d.outSize = useChecksum ? sizesForChecksum : outSize_dev;
+    dim3 grid(maxTiles, B);
+    int rc;
+    if (ft == 0) rc = launchDecodeF<0>(P, d, grid, stream);
+    else if (ft == kFloat16) rc = launchDecodeF<kFloat16>(P, d, grid, stream);
+    else if (ft == kBFloat16) rc = launchDecodeF<kBFloat16>(P, d, grid, stream);
+    else rc = launchDecodeF<kFloat32>(P, d, grid, stream);
+    if (rc) return rc;
+  }
+
+  int status = DGPU_OK;
+  if (useChecksum) {
+    // checksum the decoded data, fetch the archived checksum, compare on the
+    // host (GpuANSDecode.cuh:557-591, GpuFloatDecompress.cuh:699-733).  The
+    // decoded size (bytes, or -- float quirk -- float words used as a byte
+    // count) bounds the checksummed range.
+    DGPU_ALLOC(sums, uint32_t, arena, 2 * (size_t)B);
+    DGPU_HIP(hipMemsetAsync(sums, 0, 2 * (size_t)B * 4, stream));
+    dim3 grid(gridX(maxCapacity * (ft ? floatWordBytes(ft) : 1u), 64 * 1024, 64), B);
+    hipLaunchKernelGGL(k_checksum, grid, dim3(256), 0, stream, out, (const uint32_t*)sizesForChecksum, sums);
+    DGPU_HIP(hipGetLastError());
+    if (ft) {
+      hipLaunchKernelGGL(k_float_info, dim3(divUp(B, 128)), dim3(128), 0, stream, in, B,
+                         (uint32_t*)nullptr, (uint32_t*)nullptr, sums + B);
+    } else {
+      hipLaunchKernelGGL(k_ans_info, dim3(divUp(B, 128)), dim3(128), 0, stream, in, B,
+                         (uint32_t*)nullptr, sums + B);
+    }
+    DGPU_HIP(hipGetLastError());
+    std::vector<uint32_t> h(2 * (size_t)B);
+    std::vector<uint8_t> ok(B);
+    DGPU_HIP(hipMemcpyAsync(h.data(), sums, h.size() * 4, hipMemcpyDeviceToHost, stream));
+    DGPU_HIP(hipMemcpyAsync(ok.data(), successForChecksum, B, hipMemcpyDeviceToHost, stream));
+    DGPU_HIP(hipStreamSynchronize(stream));
+    for (uint32_t i = 0; i < B; ++i) {
+      if (ok[i] && h[i] != h[B + i]) {
+        char buf[160];
+        snprintf(buf, sizeof(buf),
+                 "Checksum mismatch in batch member %u: expected checksum %x got %x", i,
+                 h[B + i], h[i]);
+        g_lastError = buf;
+        if (errBatch) *errBatch = (int32_t)i;
+        status = DGPU_ERR_CHECKSUM_MISMATCH;
+        break;
+      }
+    }
+  }
+  if (tempUsed) *tempUsed = arena.requested();
+  return status;
+}
+
+int splitSizesToPointers(
+    const void* base, const uint32_t* splitSizes, uint32_t B, uint32_t wordBytes,
+    std::vector<uint64_t>* ptrs, std::vector<uint32_t>* sizes, uint32_t* maxSize) {
+  ptrs->resize(B);
+  sizes->resize(B);
+  uint64_t prefix = 0;
+  uint32_t mx = 0;
+  for (uint32_t i = 0; i < B; ++i) {
+    (*ptrs)[i] = (uint64_t)(uintptr_t)base + prefix * wordBytes;
+    (*sizes)[i] = splitSizes[i];
+    prefix += splitSizes[i];
+    mx = std::max(mx, splitSizes[i]);
+  }
+  *maxSize = mx;
+  return DGPU_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+// extern "C" surface
+// ===========================================================================
+extern "C" {
+
+const char* dgpu_version(void) { return "dietgpu_amd 0.1 (gfx950)"; }
+const char* dgpu_last_error(void) { return g_lastError.c_str(); }
+
+void dgpu_prof_enable(int on) {
+  ProfState& p = prof();
+  std::lock_guard<std::mutex> g(p.mu);
+  p.enabled = on != 0;
+}
+
+void dgpu_prof_reset(void) {
+  ProfState& p = prof();
+  std::lock_guard<std::mutex> g(p.mu);
+  for (auto& s : p.open) {
+    (void)hipEventDestroy(s.start);
+    (void)hipEventDestroy(s.stop);
+  }
+  p.open.clear();
+  p.acc.clear();
+}
+
+int dgpu_prof_summary(char* buf, size_t cap) {
+  ProfState& p = prof();
+  std::lock_guard<std::mutex> g(p.mu);
+  for (auto& s : p.open) {
+    float ms = 0.f;
+    if (hipEventSynchronize(s.stop) == hipSuccess && hipEventElapsedTime(&ms, s.start, s.stop) == hipSuccess) {
+      auto& a = p.acc[s.name];
+      a.first += 1;
+      a.second += ms;
+    }
+    (void)hipEventDestroy(s.start);
+    (void)hipEventDestroy(s.stop);
+  }
+  p.open.clear();
+  std::string out = "{";
+  bool first = true;
+  for (auto& kv : p.acc) {
+    char line[256];
+    snprintf(line, sizeof(line), "%s\"%s\": {\"launches\": %llu, \"total_ms\": %.6f}", first ? "" : ", ",
+             kv.first.c_str(), (unsigned long long)kv.second.first, kv.second.second);
+    out += line;
+    first = false;
+  }
+  out += "}";
+  if (out.size() + 1 > cap) return -1;
+  memcpy(buf, out.c_str(), out.size() + 1);
+  return (int)out.size();
+}
+
+uint32_t dgpu_ans_max_compressed_size(uint32_t bytes) { return maxCompressedSizeHost(bytes); }
+
+uint32_t dgpu_float_max_compressed_size(uint32_t ft, uint32_t n) {
+  return 16u + maxCompressedSizeHost(n) + floatUncompDataSize(ft, n);
+}
+
+size_t dgpu_ans_encode_temp_bytes(uint32_t B, uint32_t maxBytes) {
+  size_t tiles = tilesFor(maxBytes);
+  size_t t = 0;
+  t += alignUp((size_t)B * 20 + 8, kTempAlign);                                   // params
+  t += alignUp(ZeroLayout((size_t)B * kNumSymbols, B, (uint32_t)tiles).words * 4, kTempAlign);  // zeroed region
+  t += alignUp((size_t)B * kNumSymbols * 16, kTempAlign);                         // table
+  return t + kTempAlign;
+}
+
+size_t dgpu_ans_decode_temp_bytes(uint32_t B, uint32_t maxBytes, int probBits) {
+  (void)maxBytes;
+  size_t t = 0;
+  t += alignUp((size_t)B * 20 + 8, kTempAlign);
+  t += alignUp(((size_t)B << probBits) * 4, kTempAlign);
+  t += 3 * alignUp((size_t)B * 8, kTempAlign);  // checksum verification scratch
+  return t + kTempAlign;
+}
+
+size_t dgpu_float_compress_temp_bytes(uint32_t ft, uint32_t B, uint32_t maxFloats) {
+  (void)ft;
+  size_t t = dgpu_ans_encode_temp_bytes(B, maxFloats);
+  t += alignUp((size_t)B * roundUp(std::max(maxFloats, 1u), 16u), kTempAlign);  // exponent plane
+  return t;
+}
+
+size_t dgpu_float_decompress_temp_bytes(uint32_t ft, uint32_t B, uint32_t maxFloats, int probBits) {
+  (void)ft;
+  return dgpu_ans_decode_temp_bytes(B, maxFloats, probBits);
+}
+
+// ---- encode ----------------------------------------------------------------
+int dgpu_ans_encode_batch_stride(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, int probBits, int useChecksum,
+    uint32_t numInBatch, const void* in_dev, uint32_t inPerBatchSize, uint32_t inPerBatchStride,
+    const uint32_t* histogram_dev, void* out_dev, uint32_t outPerBatchStride,
+    uint32_t* outSize_dev, void* stream) {
+  DGPU_REQUIRE(((uintptr_t)in_dev % DGPU_ANS_REQUIRED_ALIGNMENT) == 0 &&
+                   (numInBatch <= 1 || inPerBatchStride % DGPU_ANS_REQUIRED_ALIGNMENT == 0),
+               "ANS input must be 4-byte aligned");
+  DGPU_REQUIRE(((uintptr_t)out_dev % 16) == 0 && (numInBatch <= 1 || outPerBatchStride % 16 == 0),
+               "compressed output must be 16-byte aligned");
+  BatchView in = viewStride(in_dev, inPerBatchStride, inPerBatchSize);
+  BatchView out = viewStride(out_dev, outPerBatchStride, 0);
+  return ansEncodeImpl(temp_dev, tempBytes, tempUsed, probBits, useChecksum, numInBatch, nullptr,
+                       &in, &out, inPerBatchSize, histogram_dev, outSize_dev, (hipStream_t)stream);
+}
+
+int dgpu_ans_encode_batch_pointer(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, int probBits, int useChecksum,
+    uint32_t numInBatch, const void* const* in, const uint32_t* inSize,
+    const uint32_t* histogram_dev, void* const* out, uint32_t* outSize_dev, void* stream) {
+  HostParams hp;
+  hp.inPtrs.resize(numInBatch);
+  hp.outPtrs.resize(numInBatch);
+  hp.sizes.resize(numInBatch);
+  uint32_t maxSize = 0;
+  for (uint32_t i = 0; i < numInBatch; ++i) {
+    DGPU_REQUIRE(((uintptr_t)in[i] % DGPU_ANS_REQUIRED_ALIGNMENT) == 0, "ANS input must be 4-byte aligned");
+    DGPU_REQUIRE(((uintptr_t)out[i] % 16) == 0, "compressed output must be 16-byte aligned");
+    hp.inPtrs[i] = (uint64_t)(uintptr_t)in[i];
+    hp.outPtrs[i] = (uint64_t)(uintptr_t)out[i];
+    hp.sizes[i] = inSize[i];
+    maxSize = std::max(maxSize, inSize[i]);
+  }
+  return ansEncodeImpl(temp_dev, tempBytes, tempUsed, probBits, useChecksum, numInBatch, &hp,
+                       nullptr, nullptr, maxSize, histogram_dev, outSize_dev, (hipStream_t)stream);
+}
+
+int dgpu_ans_encode_batch_split_size(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, int probBits, int useChecksum,
+    uint32_t numInBatch, const void* in_dev, const uint32_t* inSplitSizes,
+    const uint32_t* histogram_dev, void* out_dev, uint32_t outStride, uint32_t* outSize_dev,
+    void* stream) {
+  // alignment rules of GpuANSEncode.cu:132-140
+  DGPU_REQUIRE(((uintptr_t)in_dev % DGPU_ANS_REQUIRED_ALIGNMENT) == 0, "ANS input must be 4-byte aligned");
+  DGPU_REQUIRE(((uintptr_t)out_dev % 16) == 0 && (numInBatch <= 1 || outStride % 16 == 0),
+               "compressed output must be 16-byte aligned");
+  for (uint32_t i = 0; i + 1 < numInBatch; ++i) {
+    DGPU_REQUIRE(inSplitSizes[i] % DGPU_ANS_REQUIRED_ALIGNMENT == 0,
+                 "interior split sizes must be multiples of 4 bytes");
+  }
+  HostParams hp;
+  uint32_t maxSize = 0;
+  splitSizesToPointers(in_dev, inSplitSizes, numInBatch, 1, &hp.inPtrs, &hp.sizes, &maxSize);
+  hp.outPtrs.resize(numInBatch);
+  for (uint32_t i = 0; i < numInBatch; ++i) {
+    hp.outPtrs[i] = (uint64_t)(uintptr_t)out_dev + (uint64_t)i * outStride;
+  }
+  return ansEncodeImpl(temp_dev, tempBytes, tempUsed, probBits, useChecksum, numInBatch, &hp,
+                       nullptr, nullptr, maxSize, histogram_dev, outSize_dev, (hipStream_t)stream);
+}
+
+// ---- decode ----------------------------------------------------------------
+int dgpu_ans_decode_batch_stride(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, int probBits, int useChecksum,
+    uint32_t numInBatch, const void* in_dev, uint32_t inPerBatchStride, void* out_dev,
+    uint32_t outPerBatchStride, uint32_t outPerBatchCapacity, uint8_t* outSuccess_dev,
+    uint32_t* outSize_dev, void* stream, int32_t* errBatch) {
+  DGPU_REQUIRE(((uintptr_t)in_dev % 16) == 0 && (numInBatch <= 1 || inPerBatchStride % 16 == 0),
+               "compressed input must be 16-byte aligned");
+  BatchView in = viewStride(in_dev, inPerBatchStride, 0);
+  BatchView out = viewStride(out_dev, outPerBatchStride, outPerBatchCapacity);
+  return decodeImpl(temp_dev, tempBytes, tempUsed, 0, probBits, useChecksum, numInBatch, nullptr,
+                    &in, &out, outPerBatchCapacity, outSuccess_dev, outSize_dev,
+                    (hipStream_t)stream, errBatch);
+}
+
+static int decodePointerCommon(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, uint32_t ft, int probBits,
+    int useChecksum, uint32_t numInBatch, const void* const* in, void* const* out,
+    const uint32_t* outCapacity, uint8_t* outSuccess_dev, uint32_t* outSize_dev, void* stream,
+    int32_t* errBatch) {
+  HostParams hp;
+  hp.inPtrs.resize(numInBatch);
+  hp.outPtrs.resize(numInBatch);
+  hp.sizes.resize(numInBatch);
+  uint32_t maxCap = 0;
+  for (uint32_t i = 0; i < numInBatch; ++i) {
+    DGPU_REQUIRE(((uintptr_t)in[i] % 16) == 0, "compressed input must be 16-byte aligned");
+    hp.inPtrs[i] = (uint64_t)(uintptr_t)in[i];
+    hp.outPtrs[i] = (uint64_t)(uintptr_t)out[i];
+    hp.sizes[i] = outCapacity[i];
+    maxCap = std::max(maxCap, outCapacity[i]);
+  }
+  return decodeImpl(temp_dev, tempBytes, tempUsed, ft, probBits, useChecksum, numInBatch, &hp,
+                    nullptr, nullptr, maxCap, outSuccess_dev, outSize_dev, (hipStream_t)stream,
+                    errBatch);
+}
+
+int dgpu_ans_decode_batch_pointer(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, int probBits, int useChecksum,
+    uint32_t numInBatch, const void* const* in, void* const* out, const uint32_t* outCapacity,
+    uint8_t* outSuccess_dev, uint32_t* outSize_dev, void* stream, int32_t* errBatch) {
+  return decodePointerCommon(temp_dev, tempBytes, tempUsed, 0, probBits, useChecksum, numInBatch,
+                             in, out, outCapacity, outSuccess_dev, outSize_dev, stream, errBatch);
+}
+
+static int decodeSplitCommon(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, uint32_t ft, int probBits,
+    int useChecksum, uint32_t numInBatch, const void* const* in, void* out_dev,
+    const uint32_t* outSplitSizes, uint8_t* outSuccess_dev, uint32_t* outSize_dev, void* stream,
+    int32_t* errBatch) {
+  HostParams hp;
+  uint32_t maxCap = 0;
+  splitSizesToPointers(out_dev, outSplitSizes, numInBatch, ft ? floatWordBytes(ft) : 1u,
+                       &hp.outPtrs, &hp.sizes, &maxCap);
+  hp.inPtrs.resize(numInBatch);
+  for (uint32_t i = 0; i < numInBatch; ++i) {
+    DGPU_REQUIRE(((uintptr_t)in[i] % 16) == 0, "compressed input must be 16-byte aligned");
+    hp.inPtrs[i] = (uint64_t)(uintptr_t)in[i];
+  }
+  return decodeImpl(temp_dev, tempBytes, tempUsed, ft, probBits, useChecksum, numInBatch, &hp,
+                    nullptr, nullptr, maxCap, outSuccess_dev, outSize_dev, (hipStream_t)stream,
+                    errBatch);
+}
+
+int dgpu_ans_decode_batch_split_size(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, int probBits, int useChecksum,
+    uint32_t numInBatch, const void* const* in, void* out_dev, const uint32_t* outSplitSizes,
+    uint8_t* outSuccess_dev, uint32_t* outSize_dev, void* stream, int32_t* errBatch) {
+  DGPU_REQUIRE(((uintptr_t)out_dev % DGPU_ANS_REQUIRED_ALIGNMENT) == 0, "output must be 4-byte aligned");
+  for (uint32_t i = 0; i + 1 < numInBatch; ++i) {
+    DGPU_REQUIRE(outSplitSizes[i] % DGPU_ANS_REQUIRED_ALIGNMENT == 0,
+                 "interior split sizes must be multiples of 4 bytes");
+  }
+  return decodeSplitCommon(temp_dev, tempBytes, tempUsed, 0, probBits, useChecksum, numInBatch, in,
+                           out_dev, outSplitSizes, outSuccess_dev, outSize_dev, stream, errBatch);
+}
+
+// ---- info ------------------------------------------------------------------
+int dgpu_ans_get_compressed_info_device(
+    const void* const* in_dev, uint32_t numInBatch, uint32_t* outSizes_dev,
+    uint32_t* outChecksum_dev, void* stream) {
+  if (numInBatch == 0 || (!outSizes_dev && !outChecksum_dev)) return DGPU_OK;
+  BatchView in = viewPointers((const uint64_t*)in_dev, nullptr, 0);
+  hipLaunchKernelGGL(k_ans_info, dim3(divUp(numInBatch, 128)), dim3(128), 0, (hipStream_t)stream,
+                     in, numInBatch, outSizes_dev, outChecksum_dev);
+  DGPU_HIP(hipGetLastError());
+  return DGPU_OK;
+}
+
+int dgpu_ans_get_compressed_info(
+    void* temp_dev, size_t tempBytes, const void* const* in, uint32_t numInBatch,
+    uint32_t* outSizes_dev, uint32_t* outChecksum_dev, void* stream) {
+  if (numInBatch == 0 || (!outSizes_dev && !outChecksum_dev)) return DGPU_OK;
+  TempArena arena(temp_dev, tempBytes, (hipStream_t)stream);
+  HostParams hp;
+  hp.inPtrs.resize(numInBatch);
+  for (uint32_t i = 0; i < numInBatch; ++i) hp.inPtrs[i] = (uint64_t)(uintptr_t)in[i];
+  const uint64_t *inP = nullptr, *outP = nullptr;
+  const uint32_t* sz = nullptr;
+  int rc = uploadParams(arena, (hipStream_t)stream, numInBatch, hp, &inP, &outP, &sz);
+  if (rc) return rc;
+  return dgpu_ans_get_compressed_info_device((const void* const*)inP, numInBatch, outSizes_dev,
+                                             outChecksum_dev, stream);
+}
+
+int dgpu_float_get_compressed_info_device(
+    const void* const* in_dev, uint32_t numInBatch, uint32_t* outSizes_dev,
+    uint32_t* outTypes_dev, uint32_t* outChecksum_dev, void* stream) {
+  if (numInBatch == 0 || (!outSizes_dev && !outTypes_dev && !outChecksum_dev)) return DGPU_OK;
+  BatchView in = viewPointers((const uint64_t*)in_dev, nullptr, 0);
+  hipLaunchKernelGGL(k_float_info, dim3(divUp(numInBatch, 128)), dim3(128), 0, (hipStream_t)stream,
+                     in, numInBatch, outSizes_dev, outTypes_dev, outChecksum_dev);
+  DGPU_HIP(hipGetLastError());
+  return DGPU_OK;
+}
+
+int dgpu_float_get_compressed_info(
+    void* temp_dev, size_t tempBytes, const void* const* in, uint32_t numInBatch,
+    uint32_t* outSizes_dev, uint32_t* outTypes_dev, uint32_t* outChecksum_dev, void* stream) {
+  if (numInBatch == 0 || (!outSizes_dev && !outTypes_dev && !outChecksum_dev)) return DGPU_OK;
+  TempArena arena(temp_dev, tempBytes, (hipStream_t)stream);
+  HostParams hp;
+  hp.inPtrs.resize(numInBatch);
+  for (uint32_t i = 0; i < numInBatch; ++i) hp.inPtrs[i] = (uint64_t)(uintptr_t)in[i];
+  const uint64_t *inP = nullptr, *outP = nullptr;
+  const uint32_t* sz = nullptr;
+  int rc = uploadParams(arena, (hipStream_t)stream, numInBatch, hp, &inP, &outP, &sz);
+  if (rc) return rc;
+  return dgpu_float_get_compressed_info_device((const void* const*)inP, numInBatch, outSizes_dev,
+                                               outTypes_dev, outChecksum_dev, stream);
+}
+
+// ---- float codec -------------------------------------------------------------
+int dgpu_float_compress(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, uint32_t floatType, int probBits,
+    int useChecksum, uint32_t numInBatch, const void* const* in, const uint32_t* inSize,
+    void* const* out, uint32_t* outSize_dev, void* stream) {
+  DGPU_REQUIRE(validFloatType(floatType), "floatType must be float16, bfloat16 or float32");
+  HostParams hp;
+  hp.inPtrs.resize(numInBatch);
+  hp.outPtrs.resize(numInBatch);
+  hp.sizes.resize(numInBatch);
+  uint32_t maxSize = 0;
+  const uint32_t wb = floatWordBytes(floatType);
+  for (uint32_t i = 0; i < numInBatch; ++i) {
+    DGPU_REQUIRE(((uintptr_t)in[i] % wb) == 0, "float input must be float-word aligned");
+    DGPU_REQUIRE(((uintptr_t)out[i] % 16) == 0, "compressed output must be 16-byte aligned");
+    hp.inPtrs[i] = (uint64_t)(uintptr_t)in[i];
+    hp.outPtrs[i] = (uint64_t)(uintptr_t)out[i];
+    hp.sizes[i] = inSize[i];
+    maxSize = std::max(maxSize, inSize[i]);
+  }
+  return floatCompressImpl(temp_dev, tempBytes, tempUsed, floatType, probBits, useChecksum,
+                           numInBatch, hp, maxSize, outSize_dev, (hipStream_t)stream);
+}
+
+int dgpu_float_compress_split_size(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, uint32_t floatType, int probBits,
+    int useChecksum, uint32_t numInBatch, const void* in_dev, const uint32_t* inSplitSizes,
+    void* out_dev, uint32_t outStride, uint32_t* outSize_dev, void* stream) {
+  DGPU_REQUIRE(validFloatType(floatType), "floatType must be float16, bfloat16 or float32");
+  DGPU_REQUIRE(((uintptr_t)out_dev % 16) == 0 && (numInBatch <= 1 || outStride % 16 == 0),
+               "compressed output must be 16-byte aligned");
+  HostParams hp;
+  uint32_t maxSize = 0;
+  splitSizesToPointers(in_dev, inSplitSizes, numInBatch, floatWordBytes(floatType), &hp.inPtrs,
+                       &hp.sizes, &maxSize);
+  hp.outPtrs.resize(numInBatch);
+  for (uint32_t i = 0; i < numInBatch; ++i) {
+    hp.outPtrs[i] = (uint64_t)(uintptr_t)out_dev + (uint64_t)i * outStride;
+  }
+  return floatCompressImpl(temp_dev, tempBytes, tempUsed, floatType, probBits, useChecksum,
+                           numInBatch, hp, maxSize, outSize_dev, (hipStream_t)stream);
+}
+
+int dgpu_float_decompress(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, uint32_t floatType, int probBits,
+    int useChecksum, uint32_t numInBatch, const void* const* in, void* const* out,
+    const uint32_t* outCapacity, uint8_t* outSuccess_dev, uint32_t* outSize_dev, void* stream,
+    int32_t* errBatch) {
+  DGPU_REQUIRE(validFloatType(floatType), "floatType must be float16, bfloat16 or float32");
+  return decodePointerCommon(temp_dev, tempBytes, tempUsed, floatType, probBits, useChecksum,
+                             numInBatch, in, out, outCapacity, outSuccess_dev, outSize_dev, stream,
+                             errBatch);
+}
+
+int dgpu_float_decompress_split_size(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, uint32_t floatType, int probBits,
+    int useChecksum, uint32_t numInBatch, const void* const* in, void* out_dev,
+    const uint32_t* outSplitSizes, uint8_t* outSuccess_dev, uint32_t* outSize_dev, void* stream,
+    int32_t* errBatch) {
+  DGPU_REQUIRE(validFloatType(floatType), "floatType must be float16, bfloat16 or float32");
+  return decodeSplitCommon(temp_dev, tempBytes, tempUsed, floatType, probBits, useChecksum,
+                           numInBatch, in, out_dev, outSplitSizes, outSuccess_dev, outSize_dev,
+                           stream, errBatch);
+}
+
+// ---- building blocks for parity tests ----------------------------------------
+int dgpu_ans_histogram_batch_stride(
+    uint32_t numInBatch, const void* in_dev, uint32_t inPerBatchSize, uint32_t inPerBatchStride,
+    uint32_t* histogram_dev, void* stream) {
+  DGPU_REQUIRE(numInBatch <= 65535u, "numInBatch must be <= 65535");
+  if (numInBatch == 0) return DGPU_OK;
+  DGPU_HIP(hipMemsetAsync(histogram_dev, 0, (size_t)numInBatch * kNumSymbols * 4, (hipStream_t)stream));
+  BatchView in = viewStride(in_dev, inPerBatchStride, inPerBatchSize);
+  dim3 grid(gridX(inPerBatchSize, 32 * 1024, 64), numInBatch);
+  hipLaunchKernelGGL(k_histogram, grid, dim3(256), 0, (hipStream_t)stream, in, histogram_dev);
+  DGPU_HIP(hipGetLastError());
+  return DGPU_OK;
+}
+
+int dgpu_ans_calc_weights(
+    uint32_t numInBatch, int probBits, const uint32_t* sizes_dev, uint32_t uniformSize,
+    const uint32_t* histogram_dev, uint32_t* table_dev, void* stream) {
+  DGPU_REQUIRE(validProbBits(probBits), "probBits must be 9, 10 or 11");
+  if (numInBatch == 0) return DGPU_OK;
+  NormalizeArgs n;
+  n.sizes = viewPointers(nullptr, sizes_dev, uniformSize);
+  n.hist = histogram_dev;
+  n.probBits = probBits;
+  n.encTable = nullptr;
+  n.refTable = (uint4*)table_dev;
+  n.out = viewStride(nullptr, 0, 0);
+  n.writeHeader = 0;
+  n.floatType = 0;
+  n.useChecksum = 0;
+  n.checksum = nullptr;
+  n.outSize = nullptr;
+  hipLaunchKernelGGL(k_normalize, dim3(numInBatch), dim3(256), 0, (hipStream_t)stream, n);
+  DGPU_HIP(hipGetLastError());
+  return DGPU_OK;
+}
+
+}  // extern "C"

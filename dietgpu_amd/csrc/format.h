@@ -1,0 +1,101 @@
+// Wire format + batch addressing shared by every kernel.
+//
+// The archive layout is the reference's, byte for byte
+// (dietgpu/ans/GpuANSUtils.cuh:17-229, dietgpu/float/GpuFloatUtils.cuh:19-74):
+//
+//   ANS archive  = [AnsHeader 32 B][u16 pdf[256]][u32 state[nb][32]]
+//                  [uint2 blockWords[roundUp(nb,2)]][block data ...]
+//   block i data starts at u16 offset blockWords[i].y, occupies
+//   roundUp(compressedWords_i, 8) words; blockWords[i].x =
+//   (uncompressedWords_i << 16) | compressedWords_i.
+//   Float archive = [FloatHeader 16 B][non-comp plane(s), padded to 16 B]
+//                   [ANS archive of the comp (exponent) plane]
+//
+// Bytes the reference leaves indeterminate are written as zero here.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dgpu {
+
+constexpr uint32_t kNumSymbols = 256;
+constexpr uint32_t kBlockSize = 4096;      // kDefaultBlockSize, GpuANSUtils.cuh:37
+constexpr uint32_t kLanesPerBlock = 32;    // the format's interleave (kWarpSize upstream)
+constexpr uint32_t kRowsPerBlock = kBlockSize / kLanesPerBlock;
+constexpr uint32_t kStateBits = 31;        // kANSStateBits
+constexpr uint32_t kEncodedBits = 16;      // kANSEncodedBits
+constexpr uint32_t kStartState = 1u << (kStateBits - kEncodedBits);  // 2^15
+constexpr uint32_t kMinState = kStartState;
+constexpr uint32_t kAnsMagic = 0xd00du;
+constexpr uint32_t kAnsVersion = 0x0001u;
+constexpr uint32_t kFloatMagic = 0xf00fu;
+constexpr uint32_t kFloatVersion = 0x0001u;
+constexpr uint32_t kBlockAlignWords = 8;   // 16 bytes of u16
+
+constexpr uint32_t kFloat16 = 1, kBFloat16 = 2, kFloat32 = 3;
+
+// Blocks handled by one 256-thread workgroup: 4 wave64 x 2 half-waves.
+constexpr uint32_t kBlocksPerTile = 8;
+
+struct alignas(32) AnsHeader {
+  uint32_t magicAndVersion;
+  uint32_t numBlocks;
+  uint32_t totalUncompressedWords;
+  uint32_t totalCompressedWords;
+  uint32_t options;  // probBits | useChecksum << 4
+  uint32_t checksum;
+  uint32_t unused0;
+  uint32_t unused1;
+};
+static_assert(sizeof(AnsHeader) == 32, "");
+
+struct alignas(16) FloatHeader {
+  uint32_t magicAndVersion;
+  uint32_t size;     // float words
+  uint32_t options;  // floatType | useChecksum << 4
+  uint32_t checksum;
+};
+static_assert(sizeof(FloatHeader) == 16, "");
+
+__host__ __device__ constexpr uint32_t divUp(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+__host__ __device__ constexpr uint32_t roundUp(uint32_t a, uint32_t b) { return divUp(a, b) * b; }
+
+// ANSCoalescedHeader::getCompressedOverhead, GpuANSUtils.cuh:68-82
+__host__ __device__ constexpr uint32_t ansOverhead(uint32_t nb) {
+  return 32u + 2u * kNumSymbols + 128u * nb + 8u * roundUp(nb, 2u);
+}
+__host__ __device__ constexpr uint32_t ansStatesOffset() { return 32u + 2u * kNumSymbols; }
+__host__ __device__ constexpr uint32_t ansBlockWordsOffset(uint32_t nb) { return ansStatesOffset() + 128u * nb; }
+
+// FloatTypeInfo<FT>::getUncompDataSize, GpuFloatUtils.cuh:123-127,163-167,194-203
+__host__ __device__ inline uint32_t floatUncompDataSize(uint32_t ft, uint32_t n) {
+  if (ft == kFloat32) return 2u * roundUp(n, 8u) + roundUp(n, 16u);
+  return roundUp(n, 16u);
+}
+// Offset of the embedded ANS archive inside a float archive (0 for raw ANS).
+__host__ __device__ inline uint32_t ansOffsetInArchive(uint32_t ft, uint32_t n) {
+  return ft ? 16u + floatUncompDataSize(ft, n) : 0u;
+}
+__host__ __device__ inline uint32_t floatWordBytes(uint32_t ft) { return ft == kFloat32 ? 4u : 2u; }
+
+// One addressing object for every batch flavour of the reference
+// (BatchProviderStride / Pointer / SplitSize, BatchProvider.cuh:39-194):
+// either an explicit device array of addresses, or base + b * stride; either an
+// explicit device array of sizes, or one uniform size.
+struct BatchView {
+  const uint64_t* ptrs;   // device array [B] of addresses, or nullptr
+  uint64_t base;
+  uint64_t stride;
+  const uint32_t* sizes;  // device array [B], or nullptr
+  uint32_t uniformSize;
+
+  __device__ __forceinline__ uint8_t* ptr(uint32_t b) const {
+    return (uint8_t*)(ptrs ? ptrs[b] : base + (uint64_t)b * stride);
+  }
+  __device__ __forceinline__ uint32_t size(uint32_t b) const {
+    return sizes ? sizes[b] : uniformSize;
+  }
+};
+
+}  // namespace dgpu

@@ -1,0 +1,302 @@
+// Symbol statistics for the rANS coder: batched byte histogram, probability
+// normalisation to 2^probBits, checksum and header-info kernels.
+//
+// Behavioural contract = dietgpu/ans/GpuANSStatistics.cuh:21-430,
+// dietgpu/ans/GpuChecksum.cuh:26-133, dietgpu/ans/GpuANSInfo.cuh:17-37,
+// dietgpu/float/GpuFloatInfo.cuh:18-41.  The code is organised for wave64:
+// 256-thread workgroups = 4 wavefronts, DPP/shuffle reductions, LDS bins.
+#pragma once
+
+#include "format.h"
+
+namespace dgpu {
+
+__device__ __forceinline__ uint32_t waveReduceSum(uint32_t v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ uint32_t waveReduceXor(uint32_t v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v ^= __shfl_xor(v, m, 64);
+  return v;
+}
+// inclusive scan across the 64 lanes of a wavefront
+__device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v, uint32_t lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(v, d, 64);
+    if (lane >= (uint32_t)d) v += t;
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------------------
+// Histogram.  Each wavefront owns a private 256-bin LDS histogram (ds_add_u32,
+// no return); 16-byte loads with a byte-wise head/tail so any start alignment
+// works (the reference test uses stride size+11, ANSStatisticsTest.cu:52-57).
+// grid = (xBlocks, B), 256 threads.
+__device__ __forceinline__ void histAdd4(uint32_t* bins, uint32_t x) {
+  atomicAdd(&bins[x & 0xff], 1u);
+  atomicAdd(&bins[(x >> 8) & 0xff], 1u);
+  atomicAdd(&bins[(x >> 16) & 0xff], 1u);
+  atomicAdd(&bins[x >> 24], 1u);
+}
+
+__global__ __launch_bounds__(256) void k_histogram(BatchView in, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t bins[4][kNumSymbols];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t b = blockIdx.y;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) bins[w][tid] = 0;
+  __syncthreads();
+
+  uint32_t* myBins = bins[tid >> 6];
+  const uint8_t* p = in.ptr(b);
+  const uint32_t size = in.size(b);
+
+  // bytes before the first 16-byte boundary
+  uint32_t head = (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u);
+  head = head < size ? head : size;
+  const uint32_t remaining = size - head;
+  const uint32_t numVec = remaining / 16u;
+  const uint4* pv = (const uint4*)(p + head);
+
+  if (blockIdx.x == 0 && tid < head) atomicAdd(&myBins[p[tid]], 1u);
+
+  for (uint32_t i = blockIdx.x * 256u + tid; i < numVec; i += gridDim.x * 256u) {
+    uint4 v = pv[i];
+    histAdd4(myBins, v.x);
+    histAdd4(myBins, v.y);
+    histAdd4(myBins, v.z);
+    histAdd4(myBins, v.w);
+  }
+
+  if (blockIdx.x == 0) {
+    uint32_t i = numVec * 16u + tid;
+    if (i < remaining) atomicAdd(&myBins[p[head + i]], 1u);
+  }
+  __syncthreads();
+
+  uint32_t sum = bins[0][tid] + bins[1][tid] + bins[2][tid] + bins[3][tid];
+  if (sum) atomicAdd(&hist[b * kNumSymbols + tid], sum);
+}
+
+// ---------------------------------------------------------------------------
+// Checksum: XOR of all bytes, folded to 8 bits (GpuChecksum.cuh:26-93).
+// grid = (xBlocks, B), 256 threads; out[] must be zeroed first.
+// `floatWords` != 0 reproduces the float-path quirk: the provider's size is in
+// float words but is consumed as a byte count, so only the first `size` bytes
+// are covered (GpuFloatCompress.cuh:466-468).  `sizesOverride` (nullable) lets
+// the decode side checksum exactly the decoded size.
+__global__ __launch_bounds__(256) void k_checksum(
+    BatchView in, const uint32_t* __restrict__ sizesOverride, uint32_t* __restrict__ out) {
+  __shared__ uint32_t partial[4];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t b = blockIdx.y;
+  const uint8_t* p = in.ptr(b);
+  uint32_t size = sizesOverride ? sizesOverride[b] : in.size(b);
+
+  uint32_t head = (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u);
+  head = head < size ? head : size;
+  const uint32_t remaining = size - head;
+  const uint32_t numVec = remaining / 16u;
+  const uint4* pv = (const uint4*)(p + head);
+
+  uint32_t c = 0;
+  if (blockIdx.x == 0 && tid < head) c ^= p[tid];
+  for (uint32_t i = blockIdx.x * 256u + tid; i < numVec; i += gridDim.x * 256u) {
+    uint4 v = pv[i];
+    c ^= v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (blockIdx.x == 0) {
+    uint32_t i = numVec * 16u + tid;
+    if (i < remaining) c ^= p[head + i];
+  }
+  c = (c ^ (c >> 8) ^ (c >> 16) ^ (c >> 24)) & 0xffu;
+  c = waveReduceXor(c);
+  if ((tid & 63u) == 0) partial[tid >> 6] = c;
+  __syncthreads();
+  if (tid == 0) {
+    c = partial[0] ^ partial[1] ^ partial[2] ^ partial[3];
+    if (c) atomicXor(&out[b], c);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Probability normalisation (GpuANSStatistics.cuh:178-367), one 256-thread
+// workgroup per batch element.  Produces
+//   encTable[b][sym] = {thresh = pdf << (31-P), magic, cdf, (2^P - pdf) | shift << 24}
+//     -- the encoder's packed form: state' = x + cdf + div * (2^P - pdf) with
+//        div = (mulhi(x, magic) + x) >> shift; the low 24 bits feed
+//        v_mad_u32_u24 directly;
+//   refTable[b][sym] = {pdf, cdf, magic, shift} (reference layout, optional);
+// and, when `out` is given, the static part of the ANS archive header plus the
+// u16 pdf table (the fields ansEncodeCoalesce writes at
+// GpuANSEncode.cuh:553-573); totalCompressedWords and the reported size are
+// completed by the encode kernel's last tile (or here for an empty input).
+//
+// The CUB block radix sort of the reference is replaced by rank-by-counting in
+// LDS (keys (q << 16) | sym are unique, so every correct sort gives the same
+// ranks); the block scan by wave64 shuffles.
+struct NormalizeArgs {
+  BatchView sizes;           // only size(b) is used
+  const uint32_t* hist;      // [B][256]
+  int probBits;
+  uint4* encTable;           // [B][256] nullable
+  uint4* refTable;           // [B][256] nullable
+  BatchView out;             // archive base pointers (ptr(b)); valid iff writeHeader
+  uint32_t writeHeader;
+  uint32_t floatType;        // != 0: ANS archive is embedded in a float archive
+  uint32_t useChecksum;
+  const uint32_t* checksum;  // [B] nullable
+  uint32_t* outSize;         // [B] nullable
+};
+
+__global__ __launch_bounds__(256) void k_normalize(NormalizeArgs a) {
+  __shared__ uint32_t sKeys[kNumSymbols];
+  __shared__ uint32_t sSorted[kNumSymbols];
+  __shared__ uint32_t sPdf[kNumSymbols];
+  __shared__ uint32_t sWave[4];
+
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = tid >> 6;
+  const uint32_t b = blockIdx.x;
+  const uint32_t total = a.sizes.size(b);
+  const int P = a.probBits;
+  const uint32_t W = 1u << P;
+
+  uint8_t* ans = nullptr;
+  if (a.writeHeader) ans = a.out.ptr(b) + ansOffsetInArchive(a.floatType, total);
+
+  uint32_t pdf = 0, cdf = 0, magic = 0, shift = 0;
+
+  if (total != 0) {
+    const uint32_t count = a.hist[b * kNumSymbols + tid];
+    // :215  qProb = kProbWeight * ((float)count / (float)totalNum), truncated.
+    // Explicit round-to-nearest divide and multiply: no fma contraction, no
+    // approximate reciprocal.
+    float ratio = __fdiv_rn(__uint2float_rn(count), __uint2float_rn(total));
+    uint32_t q = __float2uint_rz(__fmul_rn(__uint2float_rn(W), ratio));
+    q = (count > 0 && q == 0) ? 1u : q;  // :218
+
+    uint32_t s = waveReduceSum(q);
+    if (lane == 0) sWave[wave] = s;
+    const uint32_t key = (q << 16) | tid;  // :234
+    sKeys[tid] = key;
+    __syncthreads();
+    const int qSum = (int)(sWave[0] + sWave[1] + sWave[2] + sWave[3]);
+
+    // rank in descending order = number of keys greater than mine
+    uint32_t rank = 0;
+    const uint4* k4 = (const uint4*)sKeys;
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) {
+      uint4 k = k4[i];
+      rank += (k.x > key) + (k.y > key) + (k.z > key) + (k.w > key);
+    }
+    sSorted[rank] = key;
+    __syncthreads();
+
+    // thread r now owns the entry of rank r
+    const uint32_t rk = sSorted[tid];
+    const uint32_t rsym = rk & 0xffffu;
+    uint32_t rq = rk >> 16;
+
+    int diff = (int)W - qSum;  // :256
+    if (diff > 0) {
+      // :258-274.  Each loop trip of the reference adds 1 to every entry whose
+      // SYMBOL index is < min(diff, 256); closed form of that loop:
+      rq += (uint32_t)diff / 256u + ((rsym < ((uint32_t)diff % 256u)) ? 1u : 0u);
+    } else if (diff < 0) {
+      // :275-315  subtract 1 from the smallest entries that are still > 1
+      diff = -diff;
+      while (diff > 0) {
+        int numGt1 = __syncthreads_count(rq > 1);
+        int iter = diff < numGt1 ? diff : numGt1;
+        if (iter <= 0) break;
+        int start = numGt1 - iter;
+        if ((int)tid >= start && (int)tid < numGt1) rq -= 1;
+        diff -= iter;
+      }
+    }
+
+    sPdf[rsym] = rq;  // :318-334 un-sort
+    __syncthreads();
+    pdf = sPdf[tid];
+
+    // exclusive scan -> cdf  (:336-341)
+    uint32_t incl = waveInclusiveScan(pdf, lane);
+    __syncthreads();  // sWave reuse
+    if (lane == 63) sWave[wave] = incl;
+    __syncthreads();
+    uint32_t waveBase = 0;
+    for (uint32_t w = 0; w < wave; ++w) waveBase += sWave[w];
+    cdf = waveBase + incl - pdf;
+
+    if (pdf > 0) {  // :349-358; undefined upstream for pdf == 0, never looked up
+      shift = 32u - (uint32_t)__clz((int)(pdf - 1u));  // __clz(0) == 32
+      const uint64_t one = 1;
+      uint64_t magic64 = ((one << 32) * ((one << shift) - (uint64_t)pdf)) / (uint64_t)pdf + 1;
+      magic = (uint32_t)magic64;
+    }
+  }
+
+  if (a.encTable) {
+    uint4 e;
+    e.x = pdf << (kStateBits - P);
+    e.y = magic;
+    e.z = cdf;
+    e.w = ((W - pdf) & 0xffffffu) | (shift << 24);
+    a.encTable[b * kNumSymbols + tid] = e;
+  }
+  if (a.refTable) a.refTable[b * kNumSymbols + tid] = make_uint4(pdf, cdf, magic, shift);
+
+  if (ans) {
+    ((uint16_t*)(ans + sizeof(AnsHeader)))[tid] = (uint16_t)pdf;
+    if (tid == 0) {
+      const uint32_t nb = divUp(total, kBlockSize);
+      AnsHeader h;
+      h.magicAndVersion = (kAnsMagic << 16) | kAnsVersion;
+      h.numBlocks = nb;
+      h.totalUncompressedWords = total;
+      h.totalCompressedWords = 0;  // completed by k_ans_encode's last tile
+      h.options = (uint32_t)P | (a.useChecksum ? 0x10u : 0u);
+      h.checksum = (a.useChecksum && a.checksum) ? a.checksum[b] : 0u;
+      h.unused0 = 0;
+      h.unused1 = 0;
+      *(AnsHeader*)ans = h;
+      if (nb == 0 && a.outSize) {
+        a.outSize[b] = ansOffsetInArchive(a.floatType, total) + ansOverhead(0);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Header info kernels (GpuANSInfo.cuh:17-37, GpuFloatInfo.cuh:18-41).
+// One thread per batch element.
+__global__ void k_ans_info(
+    BatchView in, uint32_t numInBatch, uint32_t* outSizes, uint32_t* outChecksum) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= numInBatch) return;
+  const AnsHeader* h = (const AnsHeader*)in.ptr(b);
+  bool ok = h->magicAndVersion == ((kAnsMagic << 16) | kAnsVersion);
+  if (outSizes) outSizes[b] = ok ? h->totalUncompressedWords : 0u;
+  if (outChecksum) outChecksum[b] = ok ? h->checksum : 0u;
+}
+
+__global__ void k_float_info(
+    BatchView in, uint32_t numInBatch, uint32_t* outSizes, uint32_t* outTypes,
+    uint32_t* outChecksum) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= numInBatch) return;
+  const FloatHeader* h = (const FloatHeader*)in.ptr(b);
+  bool ok = h->magicAndVersion == ((kFloatMagic << 16) | kFloatVersion);
+  if (outSizes) outSizes[b] = ok ? h->size : 0u;
+  if (outTypes) outTypes[b] = ok ? (h->options & 0xfu) : 0u;
+  if (outChecksum) outChecksum[b] = ok ? h->checksum : 0u;
+}
+
+}  // namespace dgpu

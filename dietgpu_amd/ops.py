@@ -1,0 +1,315 @@
+"""Tensor API of the codec: the ten ops of `torch.ops.dietgpu.*`.
+
+Mirrors dietgpu/DietGpu.cpp (schema strings at DietGpu.cpp:915-937; argument
+validation at :149-275, :310-522, :530-911) on PyTorch-ROCm tensors: same
+names, argument order, defaults, return values and error conditions
+(TORCH_CHECK -> RuntimeError).  PyTorch is only plumbing here (device memory
+and the current HIP stream); all work happens in libdietgpu_amd.so through the
+C ABI of include/dietgpu_amd.h.
+
+Extra keyword `prob_bits` (default 10, as kDefaultPrecision DietGpu.cpp:114)
+exposes the C++ API's ANSCodecConfig.probBits in {9, 10, 11}.
+"""
+import ctypes as C
+
+import torch
+
+from ._lib import check, lib
+
+FLOAT16, BFLOAT16, FLOAT32 = 1, 2, 3
+_DTYPE_TO_FT = {torch.float16: FLOAT16, torch.bfloat16: BFLOAT16, torch.float32: FLOAT32}
+_FT_TO_DTYPE = {v: k for k, v in _DTYPE_TO_FT.items()}
+K_DEFAULT_PRECISION = 10
+_U32_MAX = (1 << 32) - 1
+
+
+def _check(cond, msg="argument check failed"):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _float_type(t):
+    """getFloatTypeFromDtype, DietGpu.cpp:18-32"""
+    _check(t.dtype in _DTYPE_TO_FT, "tensor must be float16, bfloat16 or float32")
+    return _DTYPE_TO_FT[t.dtype]
+
+
+def _total_and_max(ts):
+    """getTotalAndMaxSize, DietGpu.cpp:54-73"""
+    total = mx = 0
+    for t in ts:
+        n = t.numel()
+        _check(n * t.element_size() <= _U32_MAX)
+        total += n
+        mx = max(mx, n)
+    return total, mx
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _ptr_array(ts):
+    return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def _u32_array(vals):
+    return (C.c_uint32 * len(vals))(*vals)
+
+
+def _temp(temp_mem, dev):
+    if temp_mem is None:
+        return None, 0
+    _check(temp_mem.is_cuda and temp_mem.is_contiguous())
+    _check(temp_mem.get_device() == dev)
+    return C.c_void_p(temp_mem.data_ptr()), temp_mem.numel() * temp_mem.element_size()
+
+
+# ---------------------------------------------------------------- size queries
+def max_float_compressed_output_size(ts):
+    _, mx = _total_and_max(ts)
+    return len(ts), int(lib().dgpu_float_max_compressed_size(_float_type(ts[0]), mx))
+
+
+def max_float_compressed_size(dtype, size):
+    return int(lib().dgpu_float_max_compressed_size(_float_type(dtype), size))
+
+
+def max_any_compressed_output_size(ts):
+    _, mx = _total_and_max(ts)
+    return len(ts), int(lib().dgpu_ans_max_compressed_size(mx * ts[0].element_size()))
+
+
+def max_any_compressed_size(nbytes):
+    return int(lib().dgpu_ans_max_compressed_size(nbytes))
+
+
+# -------------------------------------------------------------------- compress
+def _validate_out(out_compressed, out_compressed_bytes, rows, cols, dev, device):
+    if out_compressed is not None:
+        oc = out_compressed
+        _check(oc.dtype == torch.uint8 and oc.is_cuda and oc.is_contiguous() and oc.dim() == 2)
+        _check(oc.size(0) >= rows and oc.size(1) >= cols and oc.get_device() == dev)
+        comp = oc
+    else:
+        comp = torch.empty((rows, cols), dtype=torch.uint8, device=device)
+    if out_compressed_bytes is not None:
+        ob = out_compressed_bytes
+        _check(ob.dtype == torch.int32 and ob.is_cuda and ob.dim() == 1 and ob.is_contiguous())
+        _check(ob.size(0) >= rows and ob.get_device() == dev)
+        sizes = ob
+    else:
+        sizes = torch.empty((rows,), dtype=torch.int32, device=device)
+    return comp, sizes
+
+
+def compress_data(compress_as_float, ts_in, checksum=False, temp_mem=None, out_compressed=None,
+                  out_compressed_bytes=None, prob_bits=K_DEFAULT_PRECISION):
+    """DietGpu.cpp:149-308 -> (comp [B, maxSize] u8, sizes [B] i32, temp bytes used)."""
+    _check(len(ts_in) > 0)
+    dev = ts_in[0].get_device()
+    rows, cols = (max_float_compressed_output_size(ts_in) if compress_as_float
+                  else max_any_compressed_output_size(ts_in))
+    for t in ts_in:
+        _check(t.is_cuda and t.is_contiguous() and t.get_device() == dev)
+        if compress_as_float:
+            _check(t.dtype == ts_in[0].dtype)
+            _float_type(t)
+    with torch.cuda.device(dev):
+        comp, sizes = _validate_out(out_compressed, out_compressed_bytes, rows, cols, dev, ts_in[0].device)
+        tp, tb = _temp(temp_mem, dev)
+        in_ptrs = _ptr_array(ts_in)
+        row = comp.size(1)
+        out_ptrs = (C.c_void_p * rows)(*[comp.data_ptr() + i * row for i in range(rows)])
+        used = C.c_size_t(0)
+        if compress_as_float:
+            in_size = _u32_array([t.numel() for t in ts_in])
+            check(lib().dgpu_float_compress(
+                tp, tb, C.byref(used), _float_type(ts_in[0]), prob_bits, int(checksum), rows,
+                in_ptrs, in_size, out_ptrs, _ptr(sizes), _stream()))
+        else:
+            in_size = _u32_array([t.numel() * t.element_size() for t in ts_in])
+            check(lib().dgpu_ans_encode_batch_pointer(
+                tp, tb, C.byref(used), prob_bits, int(checksum), rows, in_ptrs, in_size, None,
+                out_ptrs, _ptr(sizes), _stream()))
+    return comp, sizes, int(used.value)
+
+
+def compress_data_split_size(compress_as_float, t_in, t_in_split_sizes, checksum=False,
+                             temp_mem=None, out_compressed=None, out_compressed_bytes=None,
+                             prob_bits=K_DEFAULT_PRECISION):
+    """DietGpu.cpp:310-452 -> (list of compressed row views, sizes, temp bytes used)."""
+    dev = t_in.get_device()
+    _check(t_in.is_cuda and t_in.is_contiguous())
+    ft = _float_type(t_in) if compress_as_float else 0
+    if not compress_as_float:
+        _check(t_in.data_ptr() % 4 == 0, "start pointer is not aligned")
+    ss = t_in_split_sizes
+    _check(ss.is_contiguous() and not ss.is_cuda and ss.dtype == torch.int32)
+    split = [int(v) for v in ss.tolist()]
+    n = len(split)
+    for i, s in enumerate(split):
+        _check(s > 0)
+        if not compress_as_float and i != n - 1:
+            _check(s % 4 == 0, "the size of an interior split is not a multiple of the alignment")
+    mx = max(split)
+    cols = (int(lib().dgpu_float_max_compressed_size(ft, mx)) if compress_as_float
+            else int(lib().dgpu_ans_max_compressed_size(mx)))
+    with torch.cuda.device(dev):
+        comp, sizes = _validate_out(out_compressed, out_compressed_bytes, n, cols, dev, t_in.device)
+        tp, tb = _temp(temp_mem, dev)
+        used = C.c_size_t(0)
+        if compress_as_float:
+            check(lib().dgpu_float_compress_split_size(
+                tp, tb, C.byref(used), ft, prob_bits, int(checksum), n, _ptr(t_in),
+                _u32_array(split), _ptr(comp), comp.size(1), _ptr(sizes), _stream()))
+        else:
+            check(lib().dgpu_ans_encode_batch_split_size(
+                tp, tb, C.byref(used), prob_bits, int(checksum), n, _ptr(t_in), _u32_array(split),
+                None, _ptr(comp), comp.size(1), _ptr(sizes), _stream()))
+        # compressedMatrixToTensors, DietGpu.cpp:77-104
+        host_sizes = sizes[:n].tolist()
+        flat = comp.view(-1)
+        outs = [flat.narrow(0, i * comp.size(1), host_sizes[i]) for i in range(n)]
+    return outs, sizes, int(used.value)
+
+
+def compress_data_simple(compress_as_float, ts_in, checksum=False, temp_mem=67108864,
+                         prob_bits=K_DEFAULT_PRECISION):
+    """DietGpu.cpp:454-522 -> list of exactly-sized compressed tensors."""
+    _check(len(ts_in) > 0)
+    scratch = None
+    if temp_mem is not None and temp_mem > 0:
+        scratch = torch.empty((temp_mem,), dtype=torch.uint8, device=ts_in[0].device)
+    comp, sizes, _ = compress_data(compress_as_float, ts_in, checksum, scratch, None, None,
+                                   prob_bits=prob_bits)
+    host = sizes.to("cpu").tolist()
+    return [comp[i, : host[i]].clone() for i in range(len(ts_in))]
+
+
+# ------------------------------------------------------------------ decompress
+def _validate_status(out_status, out_sizes, n, dev):
+    if out_status is not None:
+        _check(out_status.is_contiguous() and out_status.is_cuda and out_status.dtype == torch.uint8)
+        _check(out_status.numel() == n and out_status.get_device() == dev)
+    if out_sizes is not None:
+        _check(out_sizes.is_contiguous() and out_sizes.is_cuda and out_sizes.dtype == torch.int32)
+        _check(out_sizes.numel() == n and out_sizes.get_device() == dev)
+
+
+def _raise_checksum(rc, is_float):
+    if rc == 3:  # DGPU_ERR_CHECKSUM_MISMATCH
+        raise RuntimeError(
+            ("floatDecompress" if is_float else "ANSDecode")
+            + ": checksum mismatch seen on decoded data; archive cannot be unpacked")
+    check(rc)
+
+
+def decompress_data(compress_as_float, ts_in, ts_out, checksum=False, temp_mem=None,
+                    out_status=None, out_decompressed_words=None, prob_bits=K_DEFAULT_PRECISION):
+    """DietGpu.cpp:530-677 -> temp bytes used."""
+    _check(len(ts_in) > 0)
+    _check(len(ts_in) == len(ts_out))
+    dev = ts_in[0].get_device()
+    caps = []
+    for ti, to in zip(ts_in, ts_out):
+        _check(ti.is_cuda and ti.get_device() == dev and ti.is_contiguous())
+        _check(to.is_cuda and to.get_device() == dev and to.is_contiguous())
+        _check(ti.dtype == torch.uint8)
+        if compress_as_float:
+            _float_type(to)
+        cap = to.numel() if compress_as_float else to.numel() * to.element_size()
+        _check(cap <= _U32_MAX)
+        caps.append(cap)
+    n = len(ts_in)
+    _validate_status(out_status, out_decompressed_words, n, dev)
+    with torch.cuda.device(dev):
+        tp, tb = _temp(temp_mem, dev)
+        used = C.c_size_t(0)
+        err = C.c_int32(-1)
+        if compress_as_float:
+            rc = lib().dgpu_float_decompress(
+                tp, tb, C.byref(used), _float_type(ts_out[0]), prob_bits, int(checksum), n,
+                _ptr_array(ts_in), _ptr_array(ts_out), _u32_array(caps), _ptr(out_status),
+                _ptr(out_decompressed_words), _stream(), C.byref(err))
+        else:
+            rc = lib().dgpu_ans_decode_batch_pointer(
+                tp, tb, C.byref(used), prob_bits, int(checksum), n, _ptr_array(ts_in),
+                _ptr_array(ts_out), _u32_array(caps), _ptr(out_status),
+                _ptr(out_decompressed_words), _stream(), C.byref(err))
+        _raise_checksum(rc, compress_as_float)
+    return int(used.value)
+
+
+def decompress_data_split_size(compress_as_float, ts_in, t_out, t_out_split_sizes, checksum=False,
+                               temp_mem=None, out_status=None, out_decompressed_words=None,
+                               prob_bits=K_DEFAULT_PRECISION):
+    """DietGpu.cpp:679-816 -> temp bytes used."""
+    _check(len(ts_in) > 0)
+    dev = ts_in[0].get_device()
+    ss = t_out_split_sizes
+    _check(ss.is_contiguous() and not ss.is_cuda and ss.dtype == torch.int32)
+    split = [int(v) for v in ss.tolist()]
+    n = len(split)
+    _check(n == len(ts_in))
+    for ti, s in zip(ts_in, split):
+        _check(ti.is_cuda and ti.get_device() == dev and ti.is_contiguous() and ti.dtype == torch.uint8)
+        _check(s > 0)
+    _check(t_out.is_cuda and t_out.get_device() == dev and t_out.is_contiguous())
+    if compress_as_float:
+        _float_type(t_out)
+    _validate_status(out_status, out_decompressed_words, n, dev)
+    with torch.cuda.device(dev):
+        tp, tb = _temp(temp_mem, dev)
+        used = C.c_size_t(0)
+        err = C.c_int32(-1)
+        if compress_as_float:
+            rc = lib().dgpu_float_decompress_split_size(
+                tp, tb, C.byref(used), _float_type(t_out), prob_bits, int(checksum), n,
+                _ptr_array(ts_in), _ptr(t_out), _u32_array(split), _ptr(out_status),
+                _ptr(out_decompressed_words), _stream(), C.byref(err))
+        else:
+            rc = lib().dgpu_ans_decode_batch_split_size(
+                tp, tb, C.byref(used), prob_bits, int(checksum), n, _ptr_array(ts_in), _ptr(t_out),
+                _u32_array(split), _ptr(out_status), _ptr(out_decompressed_words), _stream(),
+                C.byref(err))
+        _raise_checksum(rc, compress_as_float)
+    return int(used.value)
+
+
+def decompress_data_simple(compress_as_float, ts_in, checksum=False, temp_mem=67108864,
+                           prob_bits=K_DEFAULT_PRECISION):
+    """DietGpu.cpp:818-911 -> list of decompressed tensors (sizes/dtypes read from the headers)."""
+    _check(len(ts_in) > 0)
+    dev = ts_in[0].get_device()
+    device = ts_in[0].device
+    n = len(ts_in)
+    for t in ts_in:
+        _check(t.is_cuda and t.get_device() == dev and t.is_contiguous())
+    with torch.cuda.device(dev):
+        scratch = None
+        if temp_mem is not None and temp_mem >= 256:  # kSDMAlignment, DietGpu.cpp:831-834
+            scratch = torch.empty((temp_mem,), dtype=torch.uint8, device=device)
+        tp, tb = _temp(scratch, dev)
+        sizes = torch.empty((n,), dtype=torch.int32, device=device)
+        types = torch.zeros((n,), dtype=torch.int32, device=device)
+        if compress_as_float:
+            check(lib().dgpu_float_get_compressed_info(
+                tp, tb, _ptr_array(ts_in), n, _ptr(sizes), _ptr(types), None, _stream()))
+        else:
+            check(lib().dgpu_ans_get_compressed_info(
+                tp, tb, _ptr_array(ts_in), n, _ptr(sizes), None, _stream()))
+        hs, ht = sizes.tolist(), types.tolist()
+        outs = []
+        for i in range(n):
+            if compress_as_float:
+                _check(ht[i] == ht[0])  # must be a consistent dtype
+                outs.append(torch.empty((hs[i],), dtype=_FT_TO_DTYPE[ht[i]], device=device))
+            else:
+                outs.append(torch.empty((hs[i],), dtype=torch.uint8, device=device))
+    decompress_data(compress_as_float, ts_in, outs, checksum, scratch, None, None, prob_bits=prob_bits)
+    return outs

@@ -1,0 +1,237 @@
+/*
+ * dietgpu_amd.h -- C ABI of the MI355X-native batched rANS / float codec.
+ *
+ * This is the drop-in boundary for the dietgpu hot path.  The reference has no
+ * C ABI (its public API is C++: dietgpu/ans/GpuANSCodec.h and
+ * dietgpu/float/GpuFloatCodec.h, taking `StackDeviceMemory&` and
+ * `cudaStream_t`); every entry point below names the reference interface it
+ * replaces.  Conventions are the reference's own (GpuANSCodec.h:61-341,
+ * GpuFloatCodec.h:103-292):
+ *
+ *   - `in` / `out` / `inSize` / `outCapacity` are HOST arrays holding DEVICE
+ *     pointers / sizes; `*_dev` arguments are device memory.
+ *   - sizes are BYTES for the ans_* calls and FLOAT WORDS for the float_* calls.
+ *   - `outSize_dev`, `outSuccess_dev`, `histogram_dev` may be NULL.
+ *   - everything is enqueued on `stream` (a hipStream_t passed as void*); no
+ *     host synchronisation happens unless a checksum has to be verified.
+ *   - ANS inputs must be 4-byte aligned (kANSRequiredAlignment); float inputs
+ *     float-word aligned; compressed buffers 16-byte aligned.
+ *   - probBits must be 9, 10 or 11.
+ *
+ * Temporary memory: the reference threads a `StackDeviceMemory&` through every
+ * call (dietgpu/utils/StackDeviceMemory.h:141-157).  Here the caller passes a
+ * raw device region (`temp_dev`, `tempBytes`; may be NULL/0).  If it is too
+ * small the library falls back to hipMalloc + a stderr warning, exactly like
+ * the reference's overflow path (StackDeviceMemory.cpp:119-139).  `tempUsed`
+ * (nullable) receives the bytes of temp memory the call needed, which is what
+ * `StackDeviceMemory::getMaxMemoryUsage()` reports upstream.  The C++ wrappers
+ * in include/dietgpu_amd/ re-create the exact `dietgpu::` signatures on top.
+ *
+ * Return value: 0 on success, a DGPU_ERR_* code otherwise.  Decode calls
+ * additionally report a checksum mismatch as DGPU_ERR_CHECKSUM_MISMATCH with
+ * the first failing batch index in `*errBatch` (ANSDecodeStatus /
+ * FloatDecompressStatus, GpuANSCodec.h:45-59, GpuFloatCodec.h:84-99).
+ */
+#ifndef DIETGPU_AMD_H
+#define DIETGPU_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGPU_OK 0
+#define DGPU_ERR_INVALID_ARGUMENT 1
+#define DGPU_ERR_HIP 2
+#define DGPU_ERR_CHECKSUM_MISMATCH 3
+
+/* FloatType, dietgpu/float/GpuFloatCodec.h:21-26 */
+#define DGPU_FLOAT_UNDEFINED 0u
+#define DGPU_FLOAT16 1u
+#define DGPU_BFLOAT16 2u
+#define DGPU_FLOAT32 3u
+
+/* kANSRequiredAlignment / kANSDefaultProbBits, GpuANSCodec.h:16-20 */
+#define DGPU_ANS_REQUIRED_ALIGNMENT 4
+#define DGPU_ANS_DEFAULT_PROB_BITS 10
+
+const char* dgpu_version(void);
+/* Text of the last error on the calling thread (HIP error string, failed
+ * precondition).  The reference aborts through glog CHECK instead. */
+const char* dgpu_last_error(void);
+
+/* ---- size queries -------------------------------------------------------- */
+/* getMaxCompressedSize, GpuANSCodec.h:22 / GpuANSEncode.cu:13-25 */
+uint32_t dgpu_ans_max_compressed_size(uint32_t uncompressedBytes);
+/* getMaxFloatCompressedSize, GpuFloatCodec.h:31 / GpuFloatCompress.cu:23-45 */
+uint32_t dgpu_float_max_compressed_size(uint32_t floatType, uint32_t numFloats);
+/* Upper bound of temp memory the matching call needs, so a caller can size
+ * `temp_dev` once and stay allocation-free (README.md:90-94). */
+size_t dgpu_ans_encode_temp_bytes(uint32_t numInBatch, uint32_t maxBytes);
+size_t dgpu_ans_decode_temp_bytes(uint32_t numInBatch, uint32_t maxBytes, int probBits);
+size_t dgpu_float_compress_temp_bytes(uint32_t floatType, uint32_t numInBatch, uint32_t maxFloats);
+size_t dgpu_float_decompress_temp_bytes(uint32_t floatType, uint32_t numInBatch, uint32_t maxFloats, int probBits);
+
+/* ---- rANS encode --------------------------------------------------------- */
+/* ansEncodeBatchStride, GpuANSCodec.h:65-98 / GpuANSEncode.cu:27-53 */
+int dgpu_ans_encode_batch_stride(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed,
+    int probBits, int useChecksum,
+    uint32_t numInBatch,
+    const void* in_dev, uint32_t inPerBatchSize, uint32_t inPerBatchStride,
+    const uint32_t* histogram_dev,
+    void* out_dev, uint32_t outPerBatchStride,
+    uint32_t* outSize_dev,
+    void* stream);
+
+/* ansEncodeBatchPointer, GpuANSCodec.h:100-128 / GpuANSEncode.cu:55-113 */
+int dgpu_ans_encode_batch_pointer(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed,
+    int probBits, int useChecksum,
+    uint32_t numInBatch,
+    const void* const* in, const uint32_t* inSize,
+    const uint32_t* histogram_dev,
+    void* const* out,
+    uint32_t* outSize_dev,
+    void* stream);
+
+/* ansEncodeBatchSplitSize, GpuANSCodec.h:130-164 / GpuANSEncode.cu:115-179 */
+int dgpu_ans_encode_batch_split_size(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed,
+    int probBits, int useChecksum,
+    uint32_t numInBatch,
+    const void* in_dev, const uint32_t* inSplitSizes,
+    const uint32_t* histogram_dev,
+    void* out_dev, uint32_t outStride,
+    uint32_t* outSize_dev,
+    void* stream);
+
+/* ---- rANS decode --------------------------------------------------------- */
+/* ansDecodeBatchStride, GpuANSCodec.h:170-226 / GpuANSDecode.cu:20-45 */
+int dgpu_ans_decode_batch_stride(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed,
+    int probBits, int useChecksum,
+    uint32_t numInBatch,
+    const void* in_dev, uint32_t inPerBatchStride,
+    void* out_dev, uint32_t outPerBatchStride, uint32_t outPerBatchCapacity,
+    uint8_t* outSuccess_dev, uint32_t* outSize_dev,
+    void* stream, int32_t* errBatch);
+
+/* ansDecodeBatchPointer, GpuANSCodec.h:228-263 / GpuANSDecode.cu:47-120 */
+int dgpu_ans_decode_batch_pointer(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed,
+    int probBits, int useChecksum,
+    uint32_t numInBatch,
+    const void* const* in,
+    void* const* out, const uint32_t* outCapacity,
+    uint8_t* outSuccess_dev, uint32_t* outSize_dev,
+    void* stream, int32_t* errBatch);
+
+/* ansDecodeBatchSplitSize, GpuANSCodec.h:265-304 / GpuANSDecode.cu:122-193 */
+int dgpu_ans_decode_batch_split_size(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed,
+    int probBits, int useChecksum,
+    uint32_t numInBatch,
+    const void* const* in,
+    void* out_dev, const uint32_t* outSplitSizes,
+    uint8_t* outSuccess_dev, uint32_t* outSize_dev,
+    void* stream, int32_t* errBatch);
+
+/* ---- rANS info ----------------------------------------------------------- */
+/* ansGetCompressedInfo, GpuANSCodec.h:310-324 / GpuANSInfo.cu:13-35 (host
+ * array of device pointers) */
+int dgpu_ans_get_compressed_info(
+    void* temp_dev, size_t tempBytes,
+    const void* const* in, uint32_t numInBatch,
+    uint32_t* outSizes_dev, uint32_t* outChecksum_dev, void* stream);
+/* ansGetCompressedInfoDevice, GpuANSCodec.h:326-341 / GpuANSInfo.cu:37-49 */
+int dgpu_ans_get_compressed_info_device(
+    const void* const* in_dev, uint32_t numInBatch,
+    uint32_t* outSizes_dev, uint32_t* outChecksum_dev, void* stream);
+
+/* ---- float codec --------------------------------------------------------- */
+/* floatCompress, GpuFloatCodec.h:103-141 / GpuFloatCompress.cu:47-101 */
+int dgpu_float_compress(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed,
+    uint32_t floatType, int probBits, int useChecksum,
+    uint32_t numInBatch,
+    const void* const* in, const uint32_t* inSize,
+    void* const* out,
+    uint32_t* outSize_dev,
+    void* stream);
+
+/* floatCompressSplitSize, GpuFloatCodec.h:143-178 / GpuFloatCompress.cu:103-159 */
+int dgpu_float_compress_split_size(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed,
+    uint32_t floatType, int probBits, int useChecksum,
+    uint32_t numInBatch,
+    const void* in_dev, const uint32_t* inSplitSizes,
+    void* out_dev, uint32_t outStride,
+    uint32_t* outSize_dev,
+    void* stream);
+
+/* floatDecompress, GpuFloatCodec.h:184-218 / GpuFloatDecompress.cu:22-115 */
+int dgpu_float_decompress(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed,
+    uint32_t floatType, int probBits, int useChecksum,
+    uint32_t numInBatch,
+    const void* const* in,
+    void* const* out, const uint32_t* outCapacity,
+    uint8_t* outSuccess_dev, uint32_t* outSize_dev,
+    void* stream, int32_t* errBatch);
+
+/* floatDecompressSplitSize, GpuFloatCodec.h:220-258 / GpuFloatDecompress.cu:117-179 */
+int dgpu_float_decompress_split_size(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed,
+    uint32_t floatType, int probBits, int useChecksum,
+    uint32_t numInBatch,
+    const void* const* in,
+    void* out_dev, const uint32_t* outSplitSizes,
+    uint8_t* outSuccess_dev, uint32_t* outSize_dev,
+    void* stream, int32_t* errBatch);
+
+/* floatGetCompressedInfo, GpuFloatCodec.h:264-277 / GpuFloatInfo.cu:17-45 */
+int dgpu_float_get_compressed_info(
+    void* temp_dev, size_t tempBytes,
+    const void* const* in, uint32_t numInBatch,
+    uint32_t* outSizes_dev, uint32_t* outTypes_dev, uint32_t* outChecksum_dev,
+    void* stream);
+/* floatGetCompressedInfoDevice, GpuFloatCodec.h:279-292 / GpuFloatInfo.cu:47-64 */
+int dgpu_float_get_compressed_info_device(
+    const void* const* in_dev, uint32_t numInBatch,
+    uint32_t* outSizes_dev, uint32_t* outTypes_dev, uint32_t* outChecksum_dev,
+    void* stream);
+
+/* ---- building blocks exposed for parity tests ----------------------------- */
+/* ansHistogramBatch, GpuANSStatistics.cuh:384-412: [B][256] u32 counts of a
+ * strided batch (any byte alignment). */
+int dgpu_ans_histogram_batch_stride(
+    uint32_t numInBatch,
+    const void* in_dev, uint32_t inPerBatchSize, uint32_t inPerBatchStride,
+    uint32_t* histogram_dev,
+    void* stream);
+/* ansCalcWeights, GpuANSStatistics.cuh:414-430: normalised {pdf,cdf,magic,shift}
+ * uint4[B][256] in the REFERENCE's table layout (the encoder itself uses a
+ * re-packed table). */
+int dgpu_ans_calc_weights(
+    uint32_t numInBatch, int probBits,
+    const uint32_t* sizes_dev, uint32_t uniformSize,
+    const uint32_t* histogram_dev,
+    uint32_t* table_dev,
+    void* stream);
+
+/* ---- instrumentation (no upstream equivalent) ------------------------------ */
+/* Per-kernel timing with HIP events recorded on the launch stream; used by
+ * bench.py for the roofline figure.  Off by default. */
+void dgpu_prof_enable(int on);
+void dgpu_prof_reset(void);
+/* Writes a JSON object {"kernel": {"launches": n, "total_ms": t}, ...} into buf
+ * (synchronises on the recorded events). Returns length, or -1 if cap is too small. */
+int dgpu_prof_summary(char* buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIETGPU_AMD_H */

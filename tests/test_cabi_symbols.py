@@ -1,0 +1,59 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports
+every function include/dietgpu_amd.h declares (no compute calls without a GPU),
+and the pure host-side size queries agree with the oracle."""
+import ctypes
+import os
+import re
+
+import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "dietgpu_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dgpu_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import dietgpu_amd
+
+    names = declared_functions()
+    assert len(names) >= 25
+    raw = ctypes.CDLL(dietgpu_amd.build.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"libdietgpu_amd.so does not export {n}"
+    # the ctypes binding covers the same set
+    assert set(names) == set(dietgpu_amd.EXPORTED_SYMBOLS)
+    dietgpu_amd.lib()
+
+
+def test_size_queries_match_oracle():
+    import dietgpu_amd
+
+    L = dietgpu_amd.lib()
+    for n in (0, 1, 4095, 4096, 4097, 1 << 20, 123456789):
+        assert L.dgpu_ans_max_compressed_size(n) == O.ans_max_compressed_size(n)
+        for ft in (1, 2, 3):
+            assert L.dgpu_float_max_compressed_size(ft, n) == O.float_max_compressed_size(ft, n)
+    assert L.dgpu_ans_max_compressed_size(1 << 20) == 1868320
+    assert L.dgpu_float_max_compressed_size(2, 524288) == 1737264
+    # temp-size queries are monotone and cover the 256 x 1 MiB configs without the 328 MiB scratch
+    t = L.dgpu_float_compress_temp_bytes(2, 256, 524288)
+    assert 128 * 1024 * 1024 < t < 160 * 1024 * 1024
+    assert L.dgpu_ans_encode_temp_bytes(256, 1 << 20) < 4 * 1024 * 1024
+
+
+def test_ops_argument_validation_without_gpu():
+    import torch
+
+    import dietgpu_amd as dg
+    import pytest
+
+    with pytest.raises(RuntimeError):
+        dg.compress_data(True, [])
+    with pytest.raises(RuntimeError):  # CPU tensors are rejected like TORCH_CHECK(t.device().type() == kCUDA)
+        dg.compress_data(False, [torch.zeros(16, dtype=torch.uint8)])
+    assert dg.max_any_compressed_size(1 << 20) == 1868320
+    assert dg.max_float_compressed_size(torch.empty(0, dtype=torch.bfloat16), 524288) == 1737264

@@ -1,0 +1,477 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle.
+
+Bit-exact everywhere (integer / byte work): compressed archives must equal the
+oracle's byte for byte, decoded data must equal the original.  Shapes follow the
+reference's own tests (ANSTest.cu:243-282, ANSStatisticsTest.cu:44-207,
+FloatTest.cu:270-311, ans_test.py, float_test.py) plus BASELINE.md's configs.
+Nothing here reads /root/reference.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+import refgen
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+FT_DTYPE = {O.FLOAT16: torch.float16, O.BFLOAT16: torch.bfloat16, O.FLOAT32: torch.float32}
+
+
+@pytest.fixture(scope="module")
+def dg():
+    import dietgpu_amd
+
+    dietgpu_amd.lib()  # fails loudly if the HIP extension is missing
+    return dietgpu_amd
+
+
+def to_dev_bytes(x):
+    return torch.from_numpy(np.ascontiguousarray(x).view(np.uint8).copy()).to(DEV)
+
+
+def words_to_tensor(ft, w):
+    t = torch.from_numpy(np.ascontiguousarray(w).view(np.int32 if ft == O.FLOAT32 else np.int16).copy()).to(DEV)
+    return t.view(FT_DTYPE[ft])
+
+
+def tensor_to_words(ft, t):
+    v = t.view(torch.int32 if ft == O.FLOAT32 else torch.int16).cpu().numpy()
+    return v.view(np.uint32 if ft == O.FLOAT32 else np.uint16)
+
+
+def gpu_ans_encode(dg, xs, prob_bits=10, checksum=False, temp=None):
+    ts = [to_dev_bytes(x) for x in xs]
+    comp, sizes, _ = dg.compress_data(False, ts, checksum, temp, prob_bits=prob_bits)
+    sizes = sizes.cpu().numpy()
+    comp = comp.cpu().numpy()
+    return [comp[i, : sizes[i]].copy() for i in range(len(xs))]
+
+
+def gpu_ans_decode(dg, archives, sizes, prob_bits=10, checksum=False):
+    ins = [to_dev_bytes(a) for a in archives]
+    outs = [torch.empty((n,), dtype=torch.uint8, device=DEV) for n in sizes]
+    status = torch.zeros((len(ins),), dtype=torch.uint8, device=DEV)
+    osz = torch.zeros((len(ins),), dtype=torch.int32, device=DEV)
+    dg.decompress_data(False, ins, outs, checksum, None, status, osz, prob_bits=prob_bits)
+    return [o.cpu().numpy() for o in outs], status.cpu().numpy(), osz.cpu().numpy()
+
+
+# ----------------------------------------------------------------- statistics
+@pytest.mark.parametrize("size", [1, 2, 11, 32, 55, 64, 99, 1000, 12345, 1234567])
+def test_histogram_unaligned(dg, size):
+    # ANSStatisticsTest.cu:44-95: batch of 3, stride = size + 11 => unaligned starts
+    B, stride = 3, size + 11
+    rng = np.random.default_rng(size)
+    buf = rng.integers(0, 256, B * stride + 64, dtype=np.uint8)
+    t = torch.from_numpy(buf).to(DEV)
+    hist = torch.zeros((B, 256), dtype=torch.int32, device=DEV)
+    for off in (0, 1, 5):
+        rc = dg.lib().dgpu_ans_histogram_batch_stride(
+            B, C.c_void_p(t.data_ptr() + off), size, stride, C.c_void_p(hist.data_ptr()),
+            C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        h = hist.cpu().numpy()
+        for b in range(B):
+            ref = np.bincount(buf[off + b * stride : off + b * stride + size], minlength=256)
+            assert (h[b] == ref).all()
+
+
+def gpu_normalize(dg, counts, totals, prob_bits):
+    B = counts.shape[0]
+    hist = torch.from_numpy(counts.astype(np.int64).astype(np.int32)).to(DEV).contiguous()
+    sizes = torch.from_numpy(np.asarray(totals, np.int64).astype(np.int32)).to(DEV)
+    table = torch.zeros((B, 256, 4), dtype=torch.int32, device=DEV)
+    rc = dg.lib().dgpu_ans_calc_weights(
+        B, prob_bits, C.c_void_p(sizes.data_ptr()), 0, C.c_void_p(hist.data_ptr()),
+        C.c_void_p(table.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    return table.cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.parametrize("prob_bits", [9, 10, 11])
+def test_normalize_matches_oracle(dg, prob_bits):
+    rng = np.random.default_rng(prob_bits)
+    rows = []
+    # reference known answers (ANSStatisticsTest.cu:127-167)
+    d = np.ones(10000, np.uint8)
+    d[:256] = np.arange(256)
+    rows.append(np.bincount(d, minlength=256))
+    rows.append(np.full(256, 64))
+    # adversarial fp32 rounding: totals near powers of two, tiny and huge counts
+    for _ in range(200):
+        k = int(rng.integers(1, 257))
+        c = np.zeros(256, np.int64)
+        idx = rng.choice(256, k, replace=False)
+        mode = rng.integers(0, 4)
+        if mode == 0:
+            c[idx] = rng.integers(1, 1 << 20, k)
+        elif mode == 1:
+            c[idx] = rng.integers(1, 4, k)
+            c[idx[0]] = int(rng.integers(1 << 20, 1 << 31))
+        elif mode == 2:
+            c[idx] = (rng.pareto(0.7, k) * 10 + 1).astype(np.int64) % (1 << 24) + 1
+        else:
+            c[idx] = 1 << int(rng.integers(0, 20))
+        rows.append(c)
+    rows.append(np.zeros(256, np.int64))  # empty element
+    counts = np.stack(rows).astype(np.uint32)
+    totals = counts.astype(np.int64).sum(1)
+    got = gpu_normalize(dg, counts, totals, prob_bits)
+    for b in range(counts.shape[0]):
+        want = O.normalize(counts[b], int(totals[b]), prob_bits)
+        live = want[:, 0] > 0
+        assert (got[b][:, 0] == want[:, 0]).all(), f"pdf row {b}"
+        assert (got[b][:, 1] == want[:, 1]).all(), f"cdf row {b}"
+        assert (got[b][live] == want[live]).all(), f"magic/shift row {b}"
+
+
+# ------------------------------------------------------------------ ANS codec
+SIZE_SETS = [[1], [1, 1], [4096, 4095, 4096], [1234, 2345, 3456], [10000, 10013, 10000]]
+
+
+@pytest.mark.parametrize("prob_bits", [9, 10, 11])
+@pytest.mark.parametrize("lam", [1.0, 10.0, 100.0, 1000.0])
+def test_ans_batch_pointer(dg, prob_bits, lam):
+    # ANSTest.cu:248-260, checksum on
+    for sizes in SIZE_SETS:
+        xs = [refgen.generate_symbols(n, lam) for n in sizes]
+        got = gpu_ans_encode(dg, xs, prob_bits, checksum=True)
+        for x, g in zip(xs, got):
+            want = O.ans_encode(x, prob_bits, use_checksum=True)
+            assert g.size % 16 == 0
+            assert g.size == want.size and (g == want).all()
+        # decode from buffers truncated to the reported size (ans_test.py:21-26)
+        outs, status, osz = gpu_ans_decode(dg, got, sizes, prob_bits, checksum=True)
+        for x, o, s, z in zip(xs, outs, status, osz):
+            assert s == 1 and z == x.size and (o == x).all()
+
+
+def test_ans_batch_pointer_large(dg):
+    # ANSTest.cu:262-275: 100 elements, sizes U[100, 10000]
+    rng = np.random.default_rng(10)
+    sizes = rng.integers(100, 10000, 100).tolist()
+    xs = [refgen.generate_symbols(n, 20.0) for n in sizes]
+    got = gpu_ans_encode(dg, xs, 10)
+    for x, g in zip(xs, got):
+        want = O.ans_encode(x, 10)
+        assert g.size == want.size and (g == want).all()
+    outs, status, _ = gpu_ans_decode(dg, got, sizes, 10)
+    assert status.all()
+    for x, o in zip(xs, outs):
+        assert (o == x).all()
+
+
+def test_ans_decodes_oracle_archives(dg):
+    # archives produced by the CPU oracle decode on the GPU (and vice versa above)
+    xs = [refgen.generate_symbols(n, 30.0) for n in (1, 33, 4096, 8191, 100000)]
+    for p in (9, 10, 11):
+        arch = [O.ans_encode(x, p) for x in xs]
+        outs, status, osz = gpu_ans_decode(dg, arch, [x.size for x in xs], p)
+        assert status.all()
+        for x, o in zip(xs, outs):
+            assert (o == x).all()
+
+
+def test_ans_batch_stride(dg):
+    # ANSTest.cu:277-282: 13 x 8208 bytes, through the stride entry points
+    B, n = 13, 8208
+    x = refgen.generate_symbols(B * n, 20.0).reshape(B, n)
+    t = torch.from_numpy(x.copy()).to(DEV)
+    lib = dg.lib()
+    stride = int(lib.dgpu_ans_max_compressed_size(n))
+    comp = torch.zeros((B, stride), dtype=torch.uint8, device=DEV)
+    sizes = torch.zeros((B,), dtype=torch.int32, device=DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.dgpu_ans_encode_batch_stride(None, 0, None, 10, 1, B, C.c_void_p(t.data_ptr()), n, n, None,
+                                          C.c_void_p(comp.data_ptr()), stride, C.c_void_p(sizes.data_ptr()), st)
+    assert rc == 0
+    hs = sizes.cpu().numpy()
+    hc = comp.cpu().numpy()
+    for b in range(B):
+        want = O.ans_encode(x[b], 10, use_checksum=True)
+        assert hs[b] == want.size and (hc[b, : hs[b]] == want).all()
+    out = torch.zeros((B, n), dtype=torch.uint8, device=DEV)
+    status = torch.zeros((B,), dtype=torch.uint8, device=DEV)
+    osz = torch.zeros((B,), dtype=torch.int32, device=DEV)
+    err = C.c_int32(-1)
+    rc = lib.dgpu_ans_decode_batch_stride(None, 0, None, 10, 1, B, C.c_void_p(comp.data_ptr()), stride,
+                                          C.c_void_p(out.data_ptr()), n, n, C.c_void_p(status.data_ptr()),
+                                          C.c_void_p(osz.data_ptr()), st, C.byref(err))
+    assert rc == 0 and err.value == -1
+    assert status.cpu().numpy().all() and (osz.cpu().numpy() == n).all()
+    assert (out.cpu().numpy() == x).all()
+
+
+def test_ans_empty(dg):
+    # ans_test.py:68-77
+    ts = [torch.empty((0,), dtype=torch.uint8, device=DEV)]
+    comp = dg.compress_data_simple(False, ts, True)
+    assert comp[0].numel() == 544
+    assert (comp[0].cpu().numpy() == O.ans_encode(np.zeros(0, np.uint8), 10, use_checksum=True)).all()
+    dec = dg.decompress_data_simple(False, comp, True)
+    assert dec[0].numel() == 0
+
+
+def test_ans_capacity_too_small(dg):
+    x = refgen.generate_symbols(5000, 20.0)
+    arch = gpu_ans_encode(dg, [x, x])
+    ins = [to_dev_bytes(a) for a in arch]
+    outs = [torch.zeros((4999,), dtype=torch.uint8, device=DEV), torch.zeros((5000,), dtype=torch.uint8, device=DEV)]
+    status = torch.zeros((2,), dtype=torch.uint8, device=DEV)
+    osz = torch.zeros((2,), dtype=torch.int32, device=DEV)
+    dg.decompress_data(False, ins, outs, False, None, status, osz)
+    assert status.cpu().tolist() == [0, 1]
+    assert osz.cpu().tolist() == [5000, 5000]  # required size is reported on failure
+    assert (outs[0].cpu().numpy() == 0).all()  # nothing written
+    assert (outs[1].cpu().numpy() == x).all()
+
+
+def test_ans_checksum_mismatch_detected(dg):
+    x = refgen.generate_symbols(20000, 20.0)
+    arch = gpu_ans_encode(dg, [x], checksum=True)[0]
+    bad = arch.copy()
+    bad[20] ^= 0x5A  # stored checksum
+    out = torch.zeros((x.size,), dtype=torch.uint8, device=DEV)
+    with pytest.raises(RuntimeError, match="checksum mismatch"):
+        dg.decompress_data(False, [to_dev_bytes(bad)], [out], True)
+    dg.decompress_data(False, [to_dev_bytes(arch)], [out], True)
+    assert (out.cpu().numpy() == x).all()
+
+
+def test_ans_temp_mem_and_usage(dg):
+    # with and without caller temp memory (ans_test.py:51-66); float32 tensors bytewise
+    temp = torch.empty((64 * 1024 * 1024,), dtype=torch.uint8, device=DEV)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    ts = [torch.randn((n,), generator=g).to(DEV) for n in (10000, 100000, 1000000)]
+    for tm in (None, temp):
+        for checksum in (False, True):
+            comp, sizes, used = dg.compress_data(False, ts, checksum, tm)
+            assert used > 0
+            trunc = [comp[i, : int(sizes[i])].clone() for i in range(len(ts))]
+            outs = [torch.empty_like(t) for t in ts]
+            status = torch.zeros((len(ts),), dtype=torch.uint8, device=DEV)
+            osz = torch.zeros((len(ts),), dtype=torch.int32, device=DEV)
+            dg.decompress_data(False, trunc, outs, checksum, tm, status, osz)
+            for t, o, s, z in zip(ts, outs, status.tolist(), osz.tolist()):
+                assert s == 1 and z == t.numel() * 4 and torch.equal(t, o)
+
+
+def test_ans_split_size(dg):
+    # ans_test.py:79-139
+    import random
+
+    random.seed(3)
+    for _ in range(3):
+        sizes = []
+        for _ in range(random.randrange(1, 15)):
+            s = random.randrange(1, 10000)
+            sizes.append(s + 4 - (s % 4))
+        t = torch.randint(0, 65, (sum(sizes),), dtype=torch.uint8, device=DEV)
+        sizes_t = torch.IntTensor(sizes)
+        splits = torch.split(t, sizes)
+        comp_ts, _, _ = dg.compress_data_split_size(False, t, sizes_t, True)
+        host = t.cpu().numpy()
+        off = 0
+        for c, s in zip(comp_ts, sizes):
+            want = O.ans_encode(host[off : off + s], 10, use_checksum=True)
+            assert c.numel() == want.size and (c.cpu().numpy() == want).all()
+            off += s
+        dec = dg.decompress_data_simple(False, [c.clone() for c in comp_ts], True)
+        for a, b in zip(splits, dec):
+            assert torch.equal(a, b)
+        out = torch.empty_like(t)
+        simple = dg.compress_data_simple(False, list(splits), True)
+        dg.decompress_data_split_size(False, simple, out, sizes_t, True)
+        assert torch.equal(t, out)
+
+
+@pytest.mark.parametrize("prob_bits", [9, 10, 11])
+def test_ans_worst_case_block(dg, prob_bits):
+    # a block of globally rare symbols: exercises the encoder's LDS stage bound
+    rng = np.random.default_rng(3)
+    x = np.zeros(1 << 20, np.uint8)
+    x[:4096] = rng.integers(1, 256, 4096, dtype=np.uint8)
+    x[40960:45056] = rng.integers(1, 256, 4096, dtype=np.uint8)
+    got = gpu_ans_encode(dg, [x], prob_bits)[0]
+    want = O.ans_encode(x, prob_bits)
+    assert got.size == want.size and (got == want).all()
+    outs, status, _ = gpu_ans_decode(dg, [got], [x.size], prob_bits)
+    assert status.all() and (outs[0] == x).all()
+
+
+# ---------------------------------------------------------------- float codec
+@pytest.mark.parametrize("ft", [O.FLOAT16, O.BFLOAT16, O.FLOAT32])
+@pytest.mark.parametrize("prob_bits", [9, 10])
+def test_float_batch(dg, ft, prob_bits):
+    # FloatTest.cu:270-284 (+ BatchSize1 :300-311)
+    rng = np.random.default_rng(ft * 100 + prob_bits)
+    for batch in (1, 3, 16, 23):
+        for mult16 in (False, True):
+            ns = []
+            for _ in range(batch):
+                n = int(rng.integers(1, 8192))
+                ns.append((n + 15) // 16 * 16 if mult16 else n)
+            ws = [refgen.generate_floats(ft, n) for n in ns]
+            ts = [words_to_tensor(ft, w) for w in ws]
+            comp, sizes, _ = dg.compress_data(True, ts, True, prob_bits=prob_bits)
+            hs = sizes.cpu().numpy()
+            hc = comp.cpu().numpy()
+            arch = []
+            for i, w in enumerate(ws):
+                want = O.float_compress(ft, w, prob_bits, use_checksum=True)
+                assert hs[i] == want.size and (hc[i, : hs[i]] == want).all(), (ft, prob_bits, batch, i)
+                arch.append(comp[i, : hs[i]].clone())
+            outs = [torch.empty_like(t) for t in ts]
+            status = torch.zeros((batch,), dtype=torch.uint8, device=DEV)
+            osz = torch.zeros((batch,), dtype=torch.int32, device=DEV)
+            dg.decompress_data(True, arch, outs, True, None, status, osz, prob_bits=prob_bits)
+            assert status.cpu().numpy().all() and osz.cpu().tolist() == ns
+            for w, o in zip(ws, outs):
+                assert (tensor_to_words(ft, o) == w).all()
+
+
+@pytest.mark.parametrize("ft", [O.FLOAT16, O.BFLOAT16, O.FLOAT32])
+def test_float_unaligned_io(dg, ft):
+    # inputs / outputs that are only float-word aligned (scalar paths)
+    n = 20000
+    w = refgen.generate_floats(ft, n + 3)
+    base = words_to_tensor(ft, w)
+    t = base[3:]
+    assert t.data_ptr() % 16 != 0
+    comp, sizes, _ = dg.compress_data(True, [t])
+    want = O.float_compress(ft, w[3:], 10)
+    assert int(sizes[0]) == want.size and (comp[0, : want.size].cpu().numpy() == want).all()
+    outbuf = torch.zeros_like(base)
+    out = outbuf[1 : 1 + n]
+    dg.decompress_data(True, [comp[0, : want.size].clone()], [out])
+    assert (tensor_to_words(ft, out) == w[3:]).all()
+
+
+def test_float_simple_and_empty(dg):
+    # float_test.py:78-108
+    for dt in (torch.float16, torch.bfloat16, torch.float32):
+        ts = [torch.randn((10000,), device=DEV).to(dt), torch.randn((100000,), device=DEV).to(dt)]
+        comp = dg.compress_data_simple(True, ts, True)
+        for c, t in zip(comp, ts):
+            assert c.numel() < t.numel() * t.element_size()
+        dec = dg.decompress_data_simple(True, comp, True)
+        for a, b in zip(ts, dec):
+            assert a.dtype == b.dtype and torch.equal(a, b)
+        e = [torch.empty((0,), dtype=dt, device=DEV)]
+        ce = dg.compress_data_simple(True, e, True)
+        assert ce[0].numel() == 16 + 544
+        de = dg.decompress_data_simple(True, ce, True)
+        assert de[0].numel() == 0 and de[0].dtype == dt
+
+
+def test_float_split_size(dg):
+    # float_test.py:110-178
+    import random
+
+    random.seed(5)
+    for dt, ft in ((torch.bfloat16, O.BFLOAT16), (torch.float16, O.FLOAT16), (torch.float32, O.FLOAT32)):
+        for align16 in (True, False):
+            sizes = []
+            for _ in range(random.randrange(1, 12)):
+                s = random.randrange(1, 10000)
+                if align16:
+                    s = (s + 15) // 16 * 16
+                sizes.append(s)
+            t = torch.randn((sum(sizes),), device=DEV).to(dt)
+            sizes_t = torch.IntTensor(sizes)
+            comp_ts, _, _ = dg.compress_data_split_size(True, t, sizes_t, True)
+            host = tensor_to_words(ft, t)
+            off = 0
+            for c, s in zip(comp_ts, sizes):
+                want = O.float_compress(ft, host[off : off + s], 10, use_checksum=True)
+                assert c.numel() == want.size and (c.cpu().numpy() == want).all()
+                off += s
+            out = torch.empty_like(t)
+            dg.decompress_data_split_size(True, [c.clone() for c in comp_ts], out, sizes_t, True)
+            assert torch.equal(t.view(torch.int16 if ft != O.FLOAT32 else torch.int32),
+                               out.view(torch.int16 if ft != O.FLOAT32 else torch.int32))
+
+
+def test_float_capacity_and_checksum(dg):
+    w = refgen.generate_floats(O.FLOAT16, 3000)
+    t = words_to_tensor(O.FLOAT16, w)
+    comp, sizes, _ = dg.compress_data(True, [t], True)
+    arch = comp[0, : int(sizes[0])].clone()
+    small = torch.zeros((2999,), dtype=torch.float16, device=DEV)
+    status = torch.ones((1,), dtype=torch.uint8, device=DEV)
+    osz = torch.zeros((1,), dtype=torch.int32, device=DEV)
+    dg.decompress_data(True, [arch], [small], False, None, status, osz)
+    assert status.item() == 0 and osz.item() == 3000
+    bad = arch.clone()
+    bad[12] ^= 0x3C  # stored float checksum
+    out = torch.empty_like(t)
+    with pytest.raises(RuntimeError, match="checksum mismatch"):
+        dg.decompress_data(True, [bad], [out], True)
+
+
+# ------------------------------------------------- BASELINE configs, full size
+def _check_rows_against_oracle(comp, sizes, rows, encode):
+    hs = sizes.cpu().numpy()
+    for i in rows:
+        want = encode(i)
+        got = comp[i, : hs[i]].cpu().numpy()
+        assert hs[i] == want.size and (got == want).all(), f"row {i}"
+
+
+def test_baseline_config2_zipf_bytes(dg):
+    B, n = 256, 1 << 20
+    x = refgen.zipf_bytes(8, n)  # 8 distinct rows, tiled to 256
+    xs = np.tile(x, (B // 8, 1))
+    t = torch.from_numpy(xs).to(DEV)
+    ts = list(t.unbind(0))
+    comp, sizes, _ = dg.compress_data(False, ts)
+    _check_rows_against_oracle(comp, sizes, [0, 3, 255], lambda i: O.ans_encode(xs[i], 10))
+    hs = sizes.cpu().numpy()
+    assert (hs[:8] == hs[8:16]).all()
+    ratio = hs.sum() / xs.size
+    assert abs(ratio - 0.695) < 0.02
+    outs = [torch.empty((n,), dtype=torch.uint8, device=DEV) for _ in range(B)]
+    dg.decompress_data(False, list(comp.unbind(0)), outs)
+    assert torch.equal(torch.stack(outs), t)
+
+
+def test_baseline_config3_bf16(dg):
+    B, n = 256, 512 * 1024
+    w = refgen.normal_bf16(B, n)
+    t = torch.from_numpy(w.view(np.int16)).to(DEV).view(torch.bfloat16)
+    ts = list(t.unbind(0))
+    comp, sizes, _ = dg.compress_data(True, ts)
+    _check_rows_against_oracle(comp, sizes, [0, 100, 255], lambda i: O.float_compress(O.BFLOAT16, w[i], 10))
+    ratio = sizes.cpu().numpy().sum() / (w.size * 2)
+    assert abs(ratio - 0.673) < 0.01
+    outs = [torch.empty((n,), dtype=torch.bfloat16, device=DEV) for _ in range(B)]
+    status = torch.zeros((B,), dtype=torch.uint8, device=DEV)
+    dg.decompress_data(True, list(comp.unbind(0)), outs, False, None, status)
+    assert status.cpu().numpy().all()
+    assert torch.equal(torch.stack(outs).view(torch.int16), t.view(torch.int16))
+
+
+def test_baseline_config4_sparse_fp16_p11(dg):
+    B, n = 256, 512 * 1024
+    w = refgen.sparse_fp16(B, n)
+    t = torch.from_numpy(w.view(np.int16)).to(DEV).view(torch.float16)
+    ts = list(t.unbind(0))
+    comp, sizes, _ = dg.compress_data(True, ts, prob_bits=11)
+    _check_rows_against_oracle(comp, sizes, [0, 77], lambda i: O.float_compress(O.FLOAT16, w[i], 11))
+    outs = [torch.empty((n,), dtype=torch.float16, device=DEV) for _ in range(B)]
+    dg.decompress_data(True, list(comp.unbind(0)), outs, prob_bits=11)
+    assert torch.equal(torch.stack(outs).view(torch.int16), t.view(torch.int16))
+
+
+def test_large_single_element(dg):
+    # float_test.py:66-76 shape class: one big tensor (many tiles -> multi-window look-back)
+    n = 40 * 1000 * 1000 + 7
+    t = torch.randn((n,), device=DEV).to(torch.bfloat16)
+    comp = dg.compress_data_simple(True, [t])
+    dec = dg.decompress_data_simple(True, comp)
+    assert torch.equal(dec[0].view(torch.int16), t.view(torch.int16))
+    assert comp[0].numel() < n * 2
