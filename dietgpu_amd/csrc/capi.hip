@@ -516,7 +516,7 @@ int floatCompressImpl(
 
 template <int P, uint32_t FT>
 int launchDecodePF(const DecodeArgs& a, dim3 grid, hipStream_t stream) {
-  DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode<P, FT>), grid, dim3(256), (4u << P) + kBlocksPerTile * kBlockSize, stream, a);
+  DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode<P, FT>), grid, dim3(256), decLdsBytes(P), stream, a);
   DGPU_HIP(hipGetLastError());
   return DGPU_OK;
 }
@@ -556,7 +556,7 @@ int decodeImpl(
     out = *strideOut;
   }
 
-  DGPU_ALLOC(lut, uint32_t, arena, (size_t)B << P);
+  DGPU_ALLOC(lut, uint2, arena, (size_t)B << P);
   DGPU_LAUNCH("k_decode_table", stream, k_decode_table, dim3(B), dim3(256), 0, stream, in, ft, P, lut);
   DGPU_HIP(hipGetLastError());
 
@@ -724,7 +724,7 @@ size_t dgpu_ans_decode_temp_bytes(uint32_t B, uint32_t maxBytes, int probBits) {
   (void)maxBytes;
   size_t t = 0;
   t += alignUp((size_t)B * 20 + 8, kTempAlign);
-  t += alignUp(((size_t)B << probBits) * 4, kTempAlign);
+  t += alignUp(((size_t)B << probBits) * 8, kTempAlign);
   t += 3 * alignUp((size_t)B * 8, kTempAlign);  // checksum verification scratch
   return t + kTempAlign;
 }

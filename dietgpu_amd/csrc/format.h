@@ -90,8 +90,13 @@ struct BatchView {
   const uint32_t* sizes;  // device array [B], or nullptr
   uint32_t uniformSize;
 
+  // The address is materialised as a GLOBAL (address space 1) pointer before it
+  // decays to a generic one: batch addresses arrive as integers, and without
+  // this the compiler can only emit FLAT loads/stores, which also tick the LDS
+  // counter (lgkmcnt) and so serialise against every LDS wait in the rANS loops.
   __device__ __forceinline__ uint8_t* ptr(uint32_t b) const {
-    return (uint8_t*)(ptrs ? ptrs[b] : base + (uint64_t)b * stride);
+    typedef __attribute__((address_space(1))) uint8_t* GlobalBytes;
+    return (uint8_t*)(GlobalBytes)(uintptr_t)(ptrs ? ptrs[b] : base + (uint64_t)b * stride);
   }
   __device__ __forceinline__ uint32_t size(uint32_t b) const {
     return sizes ? sizes[b] : uniformSize;

@@ -7,12 +7,19 @@
 //   * one wave64 decodes TWO 4 KiB blocks (lanes 0-31 / 32-63), one 64-bit
 //     ballot per row, each half counting its own 32-bit slice from the top
 //     lane down (the mirror of the encoder's ascending emission order);
-//   * the 2^P-entry decode LUT lives in LDS; decoded symbols go to a 4 KiB LDS
-//     stage per block instead of 1-byte global stores;
-//   * after the block is decoded the half-wave streams it out with 16-byte
-//     vectors: plain copy for raw bytes, or -- float codec -- joins each
-//     exponent byte with its non-compressed byte(s) read as 16-byte vectors
-//     from the archive and stores whole float words.
+//   * integer VALU ops issue at ~4 cycles per wave-instruction per SIMD on this
+//     chip (tools/microbench/valu_rate.hip), so the row loop is built to
+//     minimise VALU instructions and to keep many waves resident:
+//       - the decode LUT holds 64-bit entries {pdf | sym << 24, x - cdf}: the
+//         state update is one shift + one v_mad_u32_u24, and the symbol is
+//         already in the top byte where the float join wants it;
+//       - compressed words are staged through a 2 KiB LDS ring per block
+//         (4 x 512-byte chunks, refilled one 8-row group ahead) instead of a
+//         worst-case 5 KiB stage, so LDS no longer caps occupancy;
+//       - each decoded element is joined with its non-compressed byte(s)
+//         (prefetched a group ahead, independent of the rANS state) and stored
+//         straight to HBM: 2 VALU ops for bf16 (v_lshl_or + v_alignbit, stored
+//         with a d16_hi short store), 1 for fp16, 2 for fp32.
 #pragma once
 
 #include "format.h"
@@ -31,11 +38,14 @@ __device__ __forceinline__ const uint8_t* locateAns(const uint8_t* archive, uint
 }
 
 // ---------------------------------------------------------------------------
-// Decode LUT: lut[b][x] = (x - cdf[sym]) << 20 | pdf[sym] << 8 | sym for
-// x in [0, 2^P)  (packDecodeLookup, GpuANSDecode.cuh:34-41).  grid = B, 256
-// threads; every slot finds its symbol by binary search over the cdf in LDS.
+// Decode LUT: for x in [0, 2^P) with sym the symbol whose cdf range holds x,
+//   lut[b][x] = { pdf[sym] | sym << 24,  x - cdf[sym] }
+// (the information of packDecodeLookup, GpuANSDecode.cuh:34-41, re-packed so
+// that v_mad_u32_u24 can take word 0 directly: its low 24 bits are the pdf).
+// grid = B, 256 threads; every slot finds its symbol by binary search over the
+// cdf in LDS.
 __global__ __launch_bounds__(256) void k_decode_table(
-    BatchView in, uint32_t floatType, int probBits, uint32_t* __restrict__ lut) {
+    BatchView in, uint32_t floatType, int probBits, uint2* __restrict__ lut) {
   __shared__ uint32_t sCdf[kNumSymbols];
   __shared__ uint32_t sPdf[kNumSymbols];
   __shared__ uint32_t sWave[4];
@@ -60,7 +70,7 @@ __global__ __launch_bounds__(256) void k_decode_table(
   __syncthreads();
 
   const uint32_t slots = 1u << probBits;
-  uint32_t* out = lut + (size_t)b * slots;
+  uint2* out = lut + (size_t)b * slots;
   for (uint32_t x = tid; x < slots; x += 256u) {
     // last symbol s with cdf[s] <= x (zero-pdf symbols share the cdf of their
     // successor and are skipped by taking the last one)
@@ -72,7 +82,7 @@ __global__ __launch_bounds__(256) void k_decode_table(
       lo = le ? mid : lo;
       hi = le ? hi : mid;
     }
-    out[x] = ((x - sCdf[lo]) << 20) | (sPdf[lo] << 8) | lo;
+    out[x] = make_uint2((sPdf[lo] & 0xfffu) | (lo << 24), (x - sCdf[lo]) & 0xfffu);
   }
 }
 
@@ -81,149 +91,197 @@ struct DecodeArgs {
   BatchView in;            // archive pointers
   BatchView out;           // output pointers + capacities (bytes for raw, float words for float)
   uint32_t floatType;      // must equal the template FT
-  const uint32_t* lut;     // [B][1 << P]
+  const uint2* lut;        // [B][1 << P]
   uint8_t* outSuccess;     // [B] nullable
   uint32_t* outSize;       // [B] nullable
 };
 
-// float join, FloatTypeInfo<FT>::join (GpuFloatUtils.cuh:117-119,149-159,187-190)
-__device__ __forceinline__ uint32_t joinF16(uint32_t comp, uint32_t nc) { return (comp << 8) | nc; }
-__device__ __forceinline__ uint32_t joinBF16(uint32_t comp, uint32_t nc) {
-  return (((comp << 8) | nc) >> 1) | ((nc & 1u) << 15);
-}
-__device__ __forceinline__ uint32_t joinF32(uint32_t comp, uint32_t nc24) {
-  uint32_t v = (comp << 24) | nc24;
-  return (v >> 1) | (v << 31);
+// ---------------------------------------------------------------------------
+// Per-row sinks.  Each lane owns element row * 32 + hl of its block.  `e0` is
+// LUT word 0 = pdf | sym << 24.  The float joins are FloatTypeInfo<FT>::join
+// (GpuFloatUtils.cuh:117-119,149-159,187-190) arranged so that the result sits
+// in the TOP half of a register and is stored with a d16_hi short store; the
+// pdf bits that ride along in the low 12 bits never reach the stored half.
+template <uint32_t FT>
+struct RowSink;
+
+template <>
+struct RowSink<0> {  // raw bytes (BatchWriter, BatchProvider.cuh:16-37)
+  uint8_t* out;
+  __device__ __forceinline__ void init(uint8_t* outBase, const uint8_t*, uint32_t, size_t first, uint32_t hl) {
+    out = outBase + first + hl;
+  }
+  __device__ __forceinline__ uint32_t prefetch(uint32_t) const { return 0; }
+  __device__ __forceinline__ void store(uint32_t row, uint32_t e0, uint32_t) const {
+    out[row * 32u] = (uint8_t)(e0 >> 24);
+  }
+};
+
+template <>
+struct RowSink<kFloat16> {  // word = comp << 8 | nonComp
+  uint16_t* out;
+  const uint8_t* nc;
+  __device__ __forceinline__ void init(uint8_t* outBase, const uint8_t* archive, uint32_t, size_t first, uint32_t hl) {
+    out = (uint16_t*)outBase + first + hl;
+    nc = archive + 16u + first + hl;
+  }
+  __device__ __forceinline__ uint32_t prefetch(uint32_t row) const { return nc[row * 32u]; }
+  __device__ __forceinline__ void store(uint32_t row, uint32_t e0, uint32_t r) const {
+    const uint32_t v = (r << 16) | e0;  // [sym][nc][0000 pdf]
+    out[row * 32u] = (uint16_t)(v >> 16);
+  }
+};
+
+template <>
+struct RowSink<kBFloat16> {  // word = (comp << 8 | nonComp) >> 1 | (nonComp & 1) << 15
+  uint16_t* out;
+  const uint8_t* nc;
+  __device__ __forceinline__ void init(uint8_t* outBase, const uint8_t* archive, uint32_t, size_t first, uint32_t hl) {
+    out = (uint16_t*)outBase + first + hl;
+    nc = archive + 16u + first + hl;
+  }
+  __device__ __forceinline__ uint32_t prefetch(uint32_t row) const { return nc[row * 32u]; }
+  __device__ __forceinline__ void store(uint32_t row, uint32_t e0, uint32_t r) const {
+    const uint32_t lo = (r << 16) | e0;                                   // [sym][nc][0000 pdf]
+    const uint32_t v = __builtin_amdgcn_alignbit(r, lo, 1);               // (lo >> 1) | (r << 31)
+    out[row * 32u] = (uint16_t)(v >> 16);                                 // [sign][exp][mant7]
+  }
+};
+
+template <>
+struct RowSink<kFloat32> {  // rotr32(comp << 24 | nonComp24, 1)
+  uint32_t* out;
+  const uint16_t* nc2;  // u16 plane of roundUp(size, 8) entries
+  const uint8_t* nc1;   // then the high-byte plane
+  __device__ __forceinline__ void init(uint8_t* outBase, const uint8_t* archive, uint32_t floatSize, size_t first, uint32_t hl) {
+    out = (uint32_t*)outBase + first + hl;
+    nc2 = (const uint16_t*)(archive + 16u) + first + hl;
+    nc1 = archive + 16u + 2u * (size_t)roundUp(floatSize, 8u) + first + hl;
+  }
+  __device__ __forceinline__ uint32_t prefetch(uint32_t row) const {
+    return ((uint32_t)nc1[row * 32u] << 16) | nc2[row * 32u];
+  }
+  __device__ __forceinline__ void store(uint32_t row, uint32_t e0, uint32_t r) const {
+    const uint32_t v = (e0 & 0xff000000u) | r;
+    out[row * 32u] = __builtin_amdgcn_alignbit(v, v, 1);
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Compressed-word ring: 4 chunks of 256 words (512 bytes) per block.  Chunk k of
+// the block's data lives in slot k & 3.  Words are consumed from the top of the
+// block downwards, at most 32 per row = 256 per 8-row group = one chunk per
+// group, so at every group boundary the ring (a) receives the chunk requested
+// one group earlier and (b) requests the next lower chunk once the unread
+// position comes within 512 words of the lowest chunk it holds.  Reads of a
+// group stay within 256 words below the position at its start, which the
+// protocol guarantees to be resident (proof in DESIGN.md).
+constexpr uint32_t kRingChunkWords = 256;
+constexpr uint32_t kRingBytes = 2048;
+constexpr uint32_t kGroupRows = 8;
+
+__host__ __device__ constexpr uint32_t decLdsBytes(int P) {
+  return (8u << P) + kBlocksPerTile * kRingBytes;
 }
 
-template <int P, bool kFull>
-__device__ __forceinline__ void decodeRows(
+template <int P, uint32_t FT, bool kFull>
+__device__ __forceinline__ void decodeBlock(
     uint32_t state,
-    uint32_t n,
-    uint32_t maxRows,
-    const uint16_t* __restrict__ words,  // this half's compressed words (global)
+    uint32_t n,                    // symbols in this half's block (0 = idle half)
+    uint32_t groups,               // wave-uniform number of 8-row groups to run
+    const uint8_t* __restrict__ gwords,  // global: this half's compressed words (16-byte aligned)
     uint32_t numWords,
-    const uint32_t* __restrict__ lut,    // LDS
-    uint8_t* __restrict__ stage,         // LDS, this half's 4 KiB symbol stage
+    uint8_t* __restrict__ ring,    // LDS: this half's 2 KiB ring (2 KiB aligned within LDS)
+    uint32_t ringBase,             // byte offset of `ring` inside LDS
+    const uint2* __restrict__ lut, // LDS
+    const RowSink<FT>& sink,
     uint32_t hl,
     bool upper) {
   constexpr uint32_t kMask = (1u << P) - 1u;
-  const uint32_t laneMaskGe = ~((1u << hl) - 1u);
-  uint32_t pos = numWords;
+  const uint32_t laneMaskLt = (1u << hl) - 1u;
+  const uint32_t paddedBytes = roundUp(numWords, kBlockAlignWords) * 2u;
 
-  auto step = [&](uint32_t row, bool valid) {
-    const uint32_t e = lut[state & kMask];
-    if (valid) {
-      stage[row * 32u + hl] = (uint8_t)(e & 0xffu);
-      state = __umul24((e >> 8) & 0xfffu, state >> P) + (e >> 20);
+  // position in BYTES of the end of the unread words
+  uint32_t pos2 = numWords * 2u;
+
+  // initial fill: every chunk that intersects [numWords - 512, numWords)
+  int lowChunk = numWords ? (int)((numWords - 1u) / kRingChunkWords) + 1 : 0;  // lowest chunk requested so far (+1 = none)
+  {
+    const int stop = numWords > 512u ? (int)((numWords - 512u) / kRingChunkWords) : 0;
+    while (lowChunk > stop) {
+      --lowChunk;
+      const uint32_t off = (uint32_t)lowChunk * 512u + hl * 16u;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (off < paddedBytes) v = *(const uint4*)(gwords + off);
+      *(uint4*)(ring + ((uint32_t)lowChunk & 3u) * 512u + hl * 16u) = v;
     }
+  }
+  uint4 pending = make_uint4(0, 0, 0, 0);
+  int pendingChunk = -1;
+
+  auto step = [&](bool valid) -> uint32_t {
+    const uint2 e = lut[state & kMask];
+    if (valid) state = __umul24(e.x, state >> P) + e.y;
     const bool read = valid && (state < kMinState);
     const uint64_t vote = __ballot(read);
     const uint32_t vh = upper ? (uint32_t)(vote >> 32) : (uint32_t)vote;
+    pos2 -= 2u * __popc(vh);
     if (read) {
-      const uint32_t v = words[pos - __popc(vh & laneMaskGe)];
-      state = (state << kEncodedBits) | v;
+      // reading lanes take words from the top down in descending lane order:
+      // word index = (new position) + number of reading lanes below me
+      const uint32_t a = pos2 + 2u * __popc(vh & laneMaskLt);
+      const uint32_t w = *(const uint16_t*)(ring + (a & (kRingBytes - 1u)));
+      state = (state << kEncodedBits) | w;
     }
-    pos -= __popc(vh);
+    return e.x;
   };
+  (void)ringBase;
 
-  if (kFull) {
-#pragma unroll 8
-    for (int row = (int)kRowsPerBlock - 1; row >= 0; --row) step((uint32_t)row, true);
-  } else {
+  uint32_t preCur[kGroupRows], preNext[kGroupRows];
+  const int lastGroup = (int)groups - 1;
+#pragma unroll
+  for (int j = 0; j < (int)kGroupRows; ++j) {
+    const uint32_t row = (uint32_t)lastGroup * kGroupRows + j;
+    preCur[j] = (kFull || row * 32u + hl < n) ? sink.prefetch(row) : 0u;
+  }
+
 #pragma unroll 1
-    for (int row = (int)maxRows - 1; row >= 0; --row) {
-      step((uint32_t)row, (uint32_t)row * 32u + hl < n);
+  for (int g = lastGroup; g >= 0; --g) {
+    // non-compressed bytes for the NEXT group: independent of the decoder state
+#pragma unroll
+    for (int j = 0; j < (int)kGroupRows; ++j) {
+      const uint32_t row = (uint32_t)(g - 1) * kGroupRows + j;
+      preNext[j] = (g > 0 && (kFull || row * 32u + hl < n)) ? sink.prefetch(row) : 0u;
     }
+    // ring maintenance
+    if (pendingChunk >= 0) {
+      *(uint4*)(ring + ((uint32_t)pendingChunk & 3u) * 512u + hl * 16u) = pending;
+      pendingChunk = -1;
+    }
+    if (lowChunk > 0 && (uint32_t)lowChunk * 512u + 1024u > pos2) {
+      --lowChunk;
+      const uint32_t off = (uint32_t)lowChunk * 512u + hl * 16u;
+      pending = (off < paddedBytes) ? *(const uint4*)(gwords + off) : make_uint4(0, 0, 0, 0);
+      pendingChunk = lowChunk;
+    }
+#pragma unroll
+    for (int j = (int)kGroupRows - 1; j >= 0; --j) {
+      const uint32_t row = (uint32_t)g * kGroupRows + j;
+      const bool valid = kFull || row * 32u + hl < n;
+      const uint32_t e0 = step(valid);
+      if (valid) sink.store(row, e0, preCur[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < (int)kGroupRows; ++j) preCur[j] = preNext[j];
   }
 }
 
-// Streams one decoded block out of its LDS stage.  FT == 0: raw bytes.
-template <uint32_t FT>
-__device__ __forceinline__ void writeBlock(
-    const uint8_t* __restrict__ stage,  // LDS, n symbols
-    uint32_t n,
-    uint32_t block,
-    uint8_t* __restrict__ outBase,      // element output base
-    const uint8_t* __restrict__ archive,// float archive base (FT != 0)
-    uint32_t floatSize,
-    uint32_t hl) {
-  const size_t first = (size_t)block * kBlockSize;  // first symbol of the block
-  if (FT == 0) {
-    uint8_t* dst = outBase + first;
-    if (n == kBlockSize && (((uintptr_t)dst & 15u) == 0)) {
-#pragma unroll
-      for (uint32_t k = 0; k < 8; ++k) ((uint4*)dst)[hl + 32u * k] = ((const uint4*)stage)[hl + 32u * k];
-    } else {
-      for (uint32_t i = hl; i < n; i += 32u) dst[i] = stage[i];
-    }
-  } else if (FT == kFloat16 || FT == kBFloat16) {
-    const uint8_t* nc = archive + 16u + first;
-    uint16_t* dst = (uint16_t*)outBase + first;
-    if (n == kBlockSize && (((uintptr_t)dst & 15u) == 0)) {
-      // 16 elements per lane per step: 16 B comp (LDS) + 16 B non-comp -> 2 x 16 B out
-#pragma unroll 2
-      for (uint32_t k = 0; k < 8; ++k) {
-        const uint32_t v = hl + 32u * k;
-        const uint4 c = ((const uint4*)stage)[v];
-        const uint4 r = ((const uint4*)nc)[v];
-        const uint32_t cw[4] = {c.x, c.y, c.z, c.w};
-        const uint32_t rw[4] = {r.x, r.y, r.z, r.w};
-        uint32_t o[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          uint32_t w[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const uint32_t cb = (cw[j] >> (8 * q)) & 0xffu;
-            const uint32_t rb = (rw[j] >> (8 * q)) & 0xffu;
-            w[q] = FT == kFloat16 ? joinF16(cb, rb) : joinBF16(cb, rb);
-          }
-          o[2 * j] = w[0] | (w[1] << 16);
-          o[2 * j + 1] = w[2] | (w[3] << 16);
-        }
-        ((uint4*)dst)[2 * v] = make_uint4(o[0], o[1], o[2], o[3]);
-        ((uint4*)dst)[2 * v + 1] = make_uint4(o[4], o[5], o[6], o[7]);
-      }
-    } else {
-      for (uint32_t i = hl; i < n; i += 32u) {
-        const uint32_t cb = stage[i], rb = nc[i];
-        dst[i] = (uint16_t)(FT == kFloat16 ? joinF16(cb, rb) : joinBF16(cb, rb));
-      }
-    }
-  } else {  // kFloat32: u16 plane of roundUp(size, 8) entries, then the high-byte plane
-    const uint16_t* nc2 = (const uint16_t*)(archive + 16u) + first;
-    const uint8_t* nc1 = archive + 16u + 2u * (size_t)roundUp(floatSize, 8u) + first;
-    uint32_t* dst = (uint32_t*)outBase + first;
-    if (n == kBlockSize && (((uintptr_t)dst & 15u) == 0)) {
-      // 4 elements per lane per step
-#pragma unroll 4
-      for (uint32_t k = 0; k < 32; ++k) {
-        const uint32_t v = hl + 32u * k;
-        const uint32_t c = ((const uint32_t*)stage)[v];
-        const uint2 lo = ((const uint2*)nc2)[v];
-        const uint32_t hi = ((const uint32_t*)nc1)[v];
-        uint4 o;
-        o.x = joinF32(c & 0xffu, ((hi & 0xffu) << 16) | (lo.x & 0xffffu));
-        o.y = joinF32((c >> 8) & 0xffu, (((hi >> 8) & 0xffu) << 16) | (lo.x >> 16));
-        o.z = joinF32((c >> 16) & 0xffu, (((hi >> 16) & 0xffu) << 16) | (lo.y & 0xffffu));
-        o.w = joinF32(c >> 24, ((hi >> 24) << 16) | (lo.y >> 16));
-        ((uint4*)dst)[v] = o;
-      }
-    } else {
-      for (uint32_t i = hl; i < n; i += 32u) {
-        dst[i] = joinF32(stage[i], ((uint32_t)nc1[i] << 16) | nc2[i]);
-      }
-    }
-  }
-}
-
-// grid = (maxTiles, B), 256 threads, LDS = LUT + 8 x 4 KiB stages.
+// grid = (maxTiles, B), 256 threads, LDS = 64-bit LUT + 8 word rings.
 template <int P, uint32_t FT>
 __global__ __launch_bounds__(256) void k_ans_decode(DecodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint32_t* sLut = (uint32_t*)smem;
-  uint8_t* sStage = smem + (4u << P);
+  uint8_t* sRings = smem;                                      // 8 x 2 KiB, 2 KiB aligned
+  uint2* sLut = (uint2*)(smem + kBlocksPerTile * kRingBytes);
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
@@ -256,9 +314,8 @@ __global__ __launch_bounds__(256) void k_ans_decode(DecodeArgs a) {
   {
     const uint4* src = (const uint4*)(a.lut + ((size_t)b << P));
     uint4* dst = (uint4*)sLut;
-    for (uint32_t i = tid; i < (1u << P) / 4u; i += 256u) dst[i] = src[i];
+    for (uint32_t i = tid; i < (1u << P) / 2u; i += 256u) dst[i] = src[i];
   }
-  __syncthreads();
 
   const uint32_t block = tile * kBlocksPerTile + hw;
   const bool haveBlock = block < nb;
@@ -268,24 +325,25 @@ __global__ __launch_bounds__(256) void k_ans_decode(DecodeArgs a) {
     state = ((const uint32_t*)(ans + ansStatesOffset()))[block * 32u + hl];
     const uint2 bw = ((const uint2*)(ans + ansBlockWordsOffset(nb)))[block];
     n = bw.x >> 16;
+    n = n < kBlockSize ? n : kBlockSize;  // malformed archive guard
     numWords = bw.x & 0xffffu;
     start = bw.y;
   }
-  const uint16_t* words = (const uint16_t*)(ans + ansOverhead(nb)) + start;
-  uint8_t* stage = sStage + hw * kBlockSize;
+  const uint8_t* gwords = ans + ansOverhead(nb) + 2u * (size_t)start;
+  __syncthreads();  // LUT visible to every wave (each half-wave's ring is private to its wave)
+
+  RowSink<FT> sink;
+  sink.init(a.out.ptr(b), archive, floatSize, (size_t)block * kBlockSize, hl);
+  uint8_t* ring = sRings + hw * kRingBytes;
 
   // uniform per wave: both halves hold full blocks?
   const uint32_t nFirst = __shfl(n, 0, 64);
   const uint32_t nSecond = __shfl(n, 32, 64);
   if (nFirst == kBlockSize && nSecond == kBlockSize) {
-    decodeRows<P, true>(state, n, kRowsPerBlock, words, numWords, sLut, stage, hl, upper);
+    decodeBlock<P, FT, true>(state, n, kRowsPerBlock / kGroupRows, gwords, numWords, ring, hw * kRingBytes, sLut, sink, hl, upper);
   } else {
     const uint32_t maxN = nFirst > nSecond ? nFirst : nSecond;
-    decodeRows<P, false>(state, n, divUp(maxN, 32u), words, numWords, sLut, stage, hl, upper);
-  }
-
-  if (haveBlock) {
-    writeBlock<FT>(stage, n, block, a.out.ptr(b), archive, floatSize, hl);
+    decodeBlock<P, FT, false>(state, n, divUp(divUp(maxN, 32u), kGroupRows), gwords, numWords, ring, hw * kRingBytes, sLut, sink, hl, upper);
   }
 }
 

@@ -33,7 +33,11 @@ namespace dgpu {
 // Upper bound of u16 words one block can emit: per lane, 128 symbols of at
 // most P bits each plus the 16-bit start/end slack and the sub-bit rounding
 // slop of the state update => 8 * P + 1 words per lane.
+#ifdef DGPU_EXPERIMENT_STAGE_WORDS
+__host__ __device__ constexpr uint32_t encStageWords(int) { return DGPU_EXPERIMENT_STAGE_WORDS; }
+#else
 __host__ __device__ constexpr uint32_t encStageWords(int P) { return 32u * (8u * (uint32_t)P + 1u); }
+#endif
 __host__ __device__ constexpr uint32_t encLdsBytes(int P) {
   return 4096u                                   // packed symbol table
       + kBlocksPerTile * encStageWords(P) * 2u   // bitstream stage per half-wave
@@ -79,8 +83,7 @@ __device__ __forceinline__ uint32_t encodeRows(
   uint32_t state = kStartState;
   uint32_t outOff = 0;
 
-  auto step = [&](uint32_t sym, bool valid) {
-    const uint4 e = table[sym];
+  auto step = [&](const uint4 e, bool valid) {
     const bool write = valid && (state >= e.x);
     const uint64_t vote = __ballot(write);
     const uint32_t vh = upper ? (uint32_t)(vote >> 32) : (uint32_t)vote;
@@ -100,16 +103,28 @@ __device__ __forceinline__ uint32_t encodeRows(
   if (kFull) {
     // 8 chunks of 16 rows; chunk c+1 is in flight in registers while chunk c is
     // consumed from the LDS ring (same wave writes and reads it: LDS ops of one
-    // wave execute in order, no barrier needed).
+    // wave execute in order, no barrier needed).  Neither the symbol fetch nor
+    // the table lookup depends on the rANS state, so both are issued ahead of
+    // the dependent chain: all 16 symbols at the chunk start, table entries
+    // kAhead rows ahead.
+    constexpr int kAhead = 4;
     const uint4* src = (const uint4*)inBlock + hl;
     uint4 cur = src[0];
 #pragma unroll 1
     for (uint32_t c = 0; c < kRowsPerBlock / 16; ++c) {
       *(uint4*)(ring + hl * 16u) = cur;
       if (c + 1 < kRowsPerBlock / 16) cur = src[(c + 1) * 32u];
+      uint32_t sym[16];
 #pragma unroll
-      for (uint32_t r = 0; r < 16; ++r) {
-        step(ring[r * 32u + hl], true);
+      for (int r = 0; r < 16; ++r) sym[r] = ring[r * 32 + hl];
+      uint4 e[kAhead];
+#pragma unroll
+      for (int r = 0; r < kAhead; ++r) e[r] = table[sym[r]];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint4 cur_e = e[r % kAhead];
+        if (r + kAhead < 16) e[r % kAhead] = table[sym[r + kAhead]];
+        step(cur_e, true);
       }
     }
   } else {
@@ -118,7 +133,7 @@ __device__ __forceinline__ uint32_t encodeRows(
       const uint32_t i = row * 32u + hl;
       const bool valid = i < n;
       const uint32_t sym = valid ? inBlock[i] : 0u;
-      step(sym, valid);
+      step(table[sym], valid);
     }
   }
   stateOut = state;

@@ -9,6 +9,7 @@
 #pragma once
 
 #include "format.h"
+#include "kernels_stats.h"
 
 namespace dgpu {
 
@@ -41,13 +42,12 @@ __device__ __forceinline__ void splitWord(uint32_t w, uint32_t& comp, uint32_t& 
 // grid = (xBlocks, B), 256 threads.
 template <uint32_t FT>
 __global__ __launch_bounds__(256) void k_float_split(SplitArgs a) {
-  __shared__ uint32_t bins[4][kNumSymbols];
+  __shared__ uint32_t bins[kHistBlockWords];
   const uint32_t tid = threadIdx.x;
   const uint32_t b = blockIdx.y;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) bins[w][tid] = 0;
+  histZero(bins, tid);
   __syncthreads();
-  uint32_t* myBins = bins[tid >> 6];
+  uint32_t* myBins = histMine(bins, tid);
 
   const uint32_t n = a.in.size(b);
   const uint8_t* inBytes = a.in.ptr(b);
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_float_split(SplitArgs a) {
   }
 
   __syncthreads();
-  const uint32_t sum = bins[0][tid] + bins[1][tid] + bins[2][tid] + bins[3][tid];
+  const uint32_t sum = histFold(bins, tid);
   if (sum) atomicAdd(&a.hist[b * kNumSymbols + tid], sum);
 }
 

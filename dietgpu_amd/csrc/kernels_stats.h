@@ -32,10 +32,35 @@ __device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v, uint32_t lane)
 }
 
 // ---------------------------------------------------------------------------
-// Histogram.  Each wavefront owns a private 256-bin LDS histogram (ds_add_u32,
-// no return); 16-byte loads with a byte-wise head/tail so any start alignment
-// works (the reference test uses stride size+11, ANSStatisticsTest.cu:52-57).
-// grid = (xBlocks, B), 256 threads.
+// Histogram bins in LDS.  Entropy-coder inputs are skewed (one exponent value
+// can be a third of the data), and ds_add_u32 serialises lanes that hit the
+// same address, so every wavefront keeps kHistCopies private copies of the 256
+// bins and lane l adds into copy l % kHistCopies: a hot symbol's ~20 lanes per
+// instruction spread over 8 addresses.  Copy stride is 257 words so that the
+// same bin of different copies falls into different LDS banks
+// (bank = (copy + bin) % 32).
+constexpr uint32_t kHistCopies = 8;
+constexpr uint32_t kHistCopyStride = kNumSymbols + 1;
+constexpr uint32_t kHistWaveWords = kHistCopies * kHistCopyStride;
+constexpr uint32_t kHistBlockWords = 4 * kHistWaveWords;  // 4 wavefronts per workgroup
+
+__device__ __forceinline__ void histZero(uint32_t* bins, uint32_t tid) {
+  for (uint32_t i = tid; i < kHistBlockWords; i += 256u) bins[i] = 0;
+}
+__device__ __forceinline__ uint32_t* histMine(uint32_t* bins, uint32_t tid) {
+  return bins + (tid >> 6) * kHistWaveWords + (tid & (kHistCopies - 1u)) * kHistCopyStride;
+}
+// total of bin `tid` over all copies of all wavefronts
+__device__ __forceinline__ uint32_t histFold(const uint32_t* bins, uint32_t tid) {
+  uint32_t sum = 0;
+#pragma unroll
+  for (uint32_t c = 0; c < 4 * kHistCopies; ++c) sum += bins[c * kHistCopyStride + tid];
+  return sum;
+}
+
+// Histogram kernel: 16-byte loads with a byte-wise head/tail so any start
+// alignment works (the reference test uses stride size+11,
+// ANSStatisticsTest.cu:52-57).  grid = (xBlocks, B), 256 threads.
 __device__ __forceinline__ void histAdd4(uint32_t* bins, uint32_t x) {
   atomicAdd(&bins[x & 0xff], 1u);
   atomicAdd(&bins[(x >> 8) & 0xff], 1u);
@@ -44,14 +69,13 @@ __device__ __forceinline__ void histAdd4(uint32_t* bins, uint32_t x) {
 }
 
 __global__ __launch_bounds__(256) void k_histogram(BatchView in, uint32_t* __restrict__ hist) {
-  __shared__ uint32_t bins[4][kNumSymbols];
+  __shared__ uint32_t bins[kHistBlockWords];
   const uint32_t tid = threadIdx.x;
   const uint32_t b = blockIdx.y;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) bins[w][tid] = 0;
+  histZero(bins, tid);
   __syncthreads();
 
-  uint32_t* myBins = bins[tid >> 6];
+  uint32_t* myBins = histMine(bins, tid);
   const uint8_t* p = in.ptr(b);
   const uint32_t size = in.size(b);
 
@@ -78,7 +102,7 @@ __global__ __launch_bounds__(256) void k_histogram(BatchView in, uint32_t* __res
   }
   __syncthreads();
 
-  uint32_t sum = bins[0][tid] + bins[1][tid] + bins[2][tid] + bins[3][tid];
+  const uint32_t sum = histFold(bins, tid);
   if (sum) atomicAdd(&hist[b * kNumSymbols + tid], sum);
 }
 

@@ -43,8 +43,26 @@ def pmc(dbs, only="dgpu::"):
         print("%-50s " % n[:50] + " ".join("%16.1f" % d[c][0] if c in d else "%16s" % "-" for c in counters))
 
 
+def pmcrows(dbs, only="dgpu::"):
+    """One block per kernel, one counter per line (mean per dispatch)."""
+    acc = {}
+    for db in dbs:
+        con = sqlite3.connect(db)
+        q = "select kernel_name, counter_name, avg(value), avg(duration) from counters_collection group by kernel_name, counter_name"
+        for n, c, v, d in con.execute(q):
+            if only and only not in n:
+                continue
+            acc.setdefault(short(n), {})[c] = (v, d)
+    for n, d in sorted(acc.items()):
+        print(n)
+        for c in sorted(d):
+            print("    %-28s %16.1f   (dispatch %.1f us)" % (c, d[c][0], d[c][1] / 1e3))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "pmcrows":
+        pmcrows(sys.argv[2:])
     else:
         pmc(sys.argv[2:])
