@@ -176,6 +176,9 @@ struct RowSink<kFloat32> {  // rotr32(comp << 24 | nonComp24, 1)
 // position comes within 512 words of the lowest chunk it holds.  Reads of a
 // group stay within 256 words below the position at its start, which the
 // protocol guarantees to be resident (proof in DESIGN.md).
+typedef __attribute__((address_space(3))) uint16_t LdsU16;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4 LdsU4;
 constexpr uint32_t kRingChunkWords = 256;
 constexpr uint32_t kRingBytes = 2048;
 constexpr uint32_t kGroupRows = 8;
@@ -191,8 +194,8 @@ __device__ __forceinline__ void decodeBlock(
     uint32_t groups,               // wave-uniform number of 8-row groups to run
     const uint8_t* __restrict__ gwords,  // global: this half's compressed words (16-byte aligned)
     uint32_t numWords,
-    uint8_t* __restrict__ ring,    // LDS: this half's 2 KiB ring (2 KiB aligned within LDS)
-    uint32_t ringBase,             // byte offset of `ring` inside LDS
+    uint8_t* __restrict__ lds,     // LDS base (dynamic LDS starts at offset 0: no static __shared__ here)
+    uint32_t ringBase,             // LDS address of this half's 2 KiB ring (multiple of 2048)
     const uint2* __restrict__ lut, // LDS
     const RowSink<FT>& sink,
     uint32_t hl,
@@ -201,8 +204,8 @@ __device__ __forceinline__ void decodeBlock(
   const uint32_t laneMaskLt = (1u << hl) - 1u;
   const uint32_t paddedBytes = roundUp(numWords, kBlockAlignWords) * 2u;
 
-  // position in BYTES of the end of the unread words
-  uint32_t pos2 = numWords * 2u;
+  // unread words of this half's block
+  uint32_t posw = numWords;
 
   // initial fill: every chunk that intersects [numWords - 512, numWords)
   int lowChunk = numWords ? (int)((numWords - 1u) / kRingChunkWords) + 1 : 0;  // lowest chunk requested so far (+1 = none)
@@ -213,7 +216,7 @@ __device__ __forceinline__ void decodeBlock(
       const uint32_t off = (uint32_t)lowChunk * 512u + hl * 16u;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (off < paddedBytes) v = *(const uint4*)(gwords + off);
-      *(uint4*)(ring + ((uint32_t)lowChunk & 3u) * 512u + hl * 16u) = v;
+      *(LdsU4*)(uintptr_t)(ringBase | (((uint32_t)lowChunk & 3u) * 512u + hl * 16u)) = u32x4{v.x, v.y, v.z, v.w};
     }
   }
   uint4 pending = make_uint4(0, 0, 0, 0);
@@ -225,18 +228,20 @@ __device__ __forceinline__ void decodeBlock(
     const bool read = valid && (state < kMinState);
     const uint64_t vote = __ballot(read);
     const uint32_t vh = upper ? (uint32_t)(vote >> 32) : (uint32_t)vote;
-    pos2 -= 2u * __popc(vh);
+    posw -= __popc(vh);
     if (read) {
       // reading lanes take words from the top down in descending lane order:
       // word index = (new position) + number of reading lanes below me
-      const uint32_t a = pos2 + 2u * __popc(vh & laneMaskLt);
-      const uint32_t w = *(const uint16_t*)(ring + (a & (kRingBytes - 1u)));
+      const uint32_t idx = posw + __popc(vh & laneMaskLt);
+      const uint32_t w = *(const LdsU16*)(uintptr_t)(((idx << 1) & (kRingBytes - 1u)) | ringBase);
       state = (state << kEncodedBits) | w;
     }
     return e.x;
   };
-  (void)ringBase;
 
+  // Non-compressed bytes are fetched one whole group ahead.  The loads are
+  // unconditional (row index clamped) so that the compiler can use counted
+  // vmcnt waits instead of draining the memory queue every group.
   uint32_t preCur[kGroupRows], preNext[kGroupRows];
   const int lastGroup = (int)groups - 1;
 #pragma unroll
@@ -247,18 +252,18 @@ __device__ __forceinline__ void decodeBlock(
 
 #pragma unroll 1
   for (int g = lastGroup; g >= 0; --g) {
-    // non-compressed bytes for the NEXT group: independent of the decoder state
+    const uint32_t gNext = g > 0 ? (uint32_t)(g - 1) : 0u;
 #pragma unroll
     for (int j = 0; j < (int)kGroupRows; ++j) {
-      const uint32_t row = (uint32_t)(g - 1) * kGroupRows + j;
-      preNext[j] = (g > 0 && (kFull || row * 32u + hl < n)) ? sink.prefetch(row) : 0u;
+      const uint32_t row = gNext * kGroupRows + j;
+      preNext[j] = (kFull || row * 32u + hl < n) ? sink.prefetch(row) : 0u;
     }
     // ring maintenance
     if (pendingChunk >= 0) {
-      *(uint4*)(ring + ((uint32_t)pendingChunk & 3u) * 512u + hl * 16u) = pending;
+      *(LdsU4*)(uintptr_t)(ringBase | (((uint32_t)pendingChunk & 3u) * 512u + hl * 16u)) = u32x4{pending.x, pending.y, pending.z, pending.w};
       pendingChunk = -1;
     }
-    if (lowChunk > 0 && (uint32_t)lowChunk * 512u + 1024u > pos2) {
+    if (lowChunk > 0 && (uint32_t)lowChunk * kRingChunkWords + 512u > posw) {
       --lowChunk;
       const uint32_t off = (uint32_t)lowChunk * 512u + hl * 16u;
       pending = (off < paddedBytes) ? *(const uint4*)(gwords + off) : make_uint4(0, 0, 0, 0);
@@ -280,7 +285,7 @@ __device__ __forceinline__ void decodeBlock(
 template <int P, uint32_t FT>
 __global__ __launch_bounds__(256) void k_ans_decode(DecodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint8_t* sRings = smem;                                      // 8 x 2 KiB, 2 KiB aligned
+  // rings: 8 x 2 KiB at LDS offset 0 (2 KiB aligned), then the LUT
   uint2* sLut = (uint2*)(smem + kBlocksPerTile * kRingBytes);
 
   const uint32_t tid = threadIdx.x;
@@ -334,16 +339,18 @@ __global__ __launch_bounds__(256) void k_ans_decode(DecodeArgs a) {
 
   RowSink<FT> sink;
   sink.init(a.out.ptr(b), archive, floatSize, (size_t)block * kBlockSize, hl);
-  uint8_t* ring = sRings + hw * kRingBytes;
+  // LDS address of the dynamic segment (0: this kernel has no static LDS); the
+  // rings must be 2 KiB aligned for the and-or addressing in decodeBlock
+  const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
 
   // uniform per wave: both halves hold full blocks?
   const uint32_t nFirst = __shfl(n, 0, 64);
   const uint32_t nSecond = __shfl(n, 32, 64);
   if (nFirst == kBlockSize && nSecond == kBlockSize) {
-    decodeBlock<P, FT, true>(state, n, kRowsPerBlock / kGroupRows, gwords, numWords, ring, hw * kRingBytes, sLut, sink, hl, upper);
+    decodeBlock<P, FT, true>(state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
   } else {
     const uint32_t maxN = nFirst > nSecond ? nFirst : nSecond;
-    decodeBlock<P, FT, false>(state, n, divUp(divUp(maxN, 32u), kGroupRows), gwords, numWords, ring, hw * kRingBytes, sLut, sink, hl, upper);
+    decodeBlock<P, FT, false>(state, n, divUp(divUp(maxN, 32u), kGroupRows), gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
   }
 }
 
