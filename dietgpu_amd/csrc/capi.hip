@@ -18,7 +18,6 @@
 #include "format.h"
 #include "kernels_decode.h"
 #include "kernels_encode.h"
-#include "kernels_float.h"
 #include "kernels_stats.h"
 
 using namespace dgpu;
@@ -318,51 +317,71 @@ int uploadParams(
 // Launch sequences
 // ---------------------------------------------------------------------------
 
-template <int P>
-int launchEncodeP(const EncodeArgs& a, uint32_t tickets, hipStream_t stream) {
-  DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P>), dim3(tickets), dim3(256), encLdsBytes(P), stream, a);
+template <int P, uint32_t FT>
+int launchEncodePF(const EncodeArgs& a, uint32_t tickets, hipStream_t stream) {
+  DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT>), dim3(tickets), dim3(256), encLdsBytes(P), stream, a);
   DGPU_HIP(hipGetLastError());
   return DGPU_OK;
 }
 
-int launchEncode(int P, const EncodeArgs& a, uint32_t tickets, hipStream_t stream) {
+template <uint32_t FT>
+int launchEncodeF(int P, const EncodeArgs& a, uint32_t tickets, hipStream_t stream) {
   switch (P) {
-    case 9: return launchEncodeP<9>(a, tickets, stream);
-    case 10: return launchEncodeP<10>(a, tickets, stream);
-    default: return launchEncodeP<11>(a, tickets, stream);
+    case 9: return launchEncodePF<9, FT>(a, tickets, stream);
+    case 10: return launchEncodePF<10, FT>(a, tickets, stream);
+    default: return launchEncodePF<11, FT>(a, tickets, stream);
   }
 }
 
-// Shared tail of every encode entry point: [checksum] -> [histogram] ->
-// normalise -> encode.  `symbols` is the byte plane that is entropy coded.
-//   floatType == 0: symbols == the caller's input, archive == ANS archive.
-//   floatType != 0: symbols == exponent plane in temp memory (already filled
-//     by k_float_split together with `hist`), archive == float archive.
-int encodeCommon(
-    TempArena& arena, hipStream_t stream, int P, bool ansChecksum, uint32_t B,
-    const BatchView& symbols, const BatchView& sizes, const BatchView& archives,
-    uint32_t floatType, uint32_t maxSize, const uint32_t* hist_dev /*may be null*/,
-    uint32_t* zeroRegion, size_t zeroWords, uint32_t* histTemp, uint32_t* checksumTemp,
-    uint64_t* tileDesc, uint32_t* ticket, uint32_t maxTiles, bool zeroAlreadyDone,
-    uint32_t* outSize_dev) {
-  if (!zeroAlreadyDone) {
-    DGPU_HIP(hipMemsetAsync(zeroRegion, 0, zeroWords * 4, stream));
+int launchEncode(int P, uint32_t ft, const EncodeArgs& a, uint32_t tickets, hipStream_t stream) {
+  switch (ft) {
+    case 0: return launchEncodeF<0>(P, a, tickets, stream);
+    case kFloat16: return launchEncodeF<kFloat16>(P, a, tickets, stream);
+    case kBFloat16: return launchEncodeF<kBFloat16>(P, a, tickets, stream);
+    default: return launchEncodeF<kFloat32>(P, a, tickets, stream);
   }
-  if (ansChecksum) {
+}
+
+// Shared tail of every encode entry point: [checksum] -> histogram ->
+// normalise -> encode.  `in` holds raw bytes (floatType == 0: the ANS archive is
+// the whole output) or float words (floatType != 0: the encoder splits them on
+// the fly, the archive is a float archive).  The zero region has been cleared.
+int encodeCommon(
+    TempArena& arena, hipStream_t stream, int P, bool useChecksum, uint32_t B,
+    const BatchView& in, const BatchView& archives, uint32_t floatType, uint32_t maxSize,
+    const uint32_t* hist_dev /*may be null*/, uint32_t* histTemp, uint32_t* checksumTemp,
+    uint64_t* tileDesc, uint32_t* ticket, uint32_t maxTiles, uint32_t* outSize_dev) {
+  const uint32_t wordBytes = floatType ? floatWordBytes(floatType) : 1u;
+  if (useChecksum) {
+    // Float quirk kept from the reference (GpuFloatCompress.cuh:466-468): the
+    // size in float WORDS is consumed as a BYTE count by the checksum.
     dim3 grid(gridX(maxSize, 64 * 1024, 64), B);
-    DGPU_LAUNCH("k_checksum", stream, k_checksum, grid, dim3(256), 0, stream, symbols, (const uint32_t*)nullptr, checksumTemp);
+    DGPU_LAUNCH("k_checksum", stream, k_checksum, grid, dim3(256), 0, stream, in, (const uint32_t*)nullptr, checksumTemp);
     DGPU_HIP(hipGetLastError());
   }
   if (!hist_dev) {
-    dim3 grid(gridX(maxSize, 32 * 1024, 64), B);
-    DGPU_LAUNCH("k_histogram", stream, k_histogram, grid, dim3(256), 0, stream, symbols, histTemp);
+    dim3 grid(gridX(maxSize * wordBytes, 32 * 1024, 64), B);
+    switch (floatType) {
+      case 0:
+        DGPU_LAUNCH("k_histogram", stream, k_histogram, grid, dim3(256), 0, stream, in, histTemp);
+        break;
+      case kFloat16:
+        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kFloat16>), grid, dim3(256), 0, stream, in, histTemp);
+        break;
+      case kBFloat16:
+        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kBFloat16>), grid, dim3(256), 0, stream, in, histTemp);
+        break;
+      default:
+        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kFloat32>), grid, dim3(256), 0, stream, in, histTemp);
+        break;
+    }
     DGPU_HIP(hipGetLastError());
     hist_dev = histTemp;
   }
   DGPU_ALLOC(table, uint4, arena, (size_t)B * kNumSymbols);
   {
     NormalizeArgs n;
-    n.sizes = sizes;
+    n.sizes = in;
     n.hist = hist_dev;
     n.probBits = P;
     n.encTable = table;
@@ -370,24 +389,26 @@ int encodeCommon(
     n.out = archives;
     n.writeHeader = 1;
     n.floatType = floatType;
-    n.useChecksum = ansChecksum ? 1 : 0;
-    n.checksum = ansChecksum ? checksumTemp : nullptr;
+    // ANS-level checksums are not used in float mode (GpuFloatCodec.h:50)
+    n.useChecksum = (useChecksum && !floatType) ? 1 : 0;
+    n.checksum = (useChecksum && !floatType) ? checksumTemp : nullptr;
     n.outSize = outSize_dev;
+    n.floatUseChecksum = (useChecksum && floatType) ? 1 : 0;
     DGPU_LAUNCH("k_normalize", stream, k_normalize, dim3(B), dim3(256), 0, stream, n);
     DGPU_HIP(hipGetLastError());
   }
   if (maxTiles > 0) {
     EncodeArgs e;
-    e.in = symbols;
+    e.in = in;
     e.out = archives;
-    e.sizes = sizes;
-    e.floatType = floatType;
     e.encTable = table;
     e.maxTiles = maxTiles;
     e.tileDesc = tileDesc;
     e.ticket = ticket;
     e.outSize = outSize_dev;
-    int rc = launchEncode(P, e, B * maxTiles, stream);
+    e.useChecksum = (useChecksum && floatType) ? 1 : 0;
+    e.checksum = (useChecksum && floatType) ? checksumTemp : nullptr;
+    int rc = launchEncode(P, floatType, e, B * maxTiles, stream);
     if (rc) return rc;
   }
   return DGPU_OK;
@@ -440,16 +461,12 @@ int ansEncodeImpl(
   uint32_t* ticket = zero + zl.ticketAt;
   uint64_t* tileDesc = (uint64_t*)(zero + zl.descAt);
 
+  DGPU_HIP(hipMemsetAsync(zero, 0, zeroWords * 4, stream));
   int rc = encodeCommon(
-      arena, stream, P, useChecksum != 0, B, in, in, out, 0, maxSize, histogram_dev, zero,
-      zeroWords, histTemp, checksumTemp, tileDesc, ticket, maxTiles, false, outSize_dev);
+      arena, stream, P, useChecksum != 0, B, in, out, 0, maxSize, histogram_dev, histTemp,
+      checksumTemp, tileDesc, ticket, maxTiles, outSize_dev);
   if (tempUsed) *tempUsed = arena.requested();
   return rc;
-}
-
-template <uint32_t FT>
-void launchSplitFT(const SplitArgs& a, dim3 grid, hipStream_t stream) {
-  DGPU_LAUNCH("k_float_split", stream, (k_float_split<FT>), grid, dim3(256), 0, stream, a);
 }
 
 int floatCompressImpl(
@@ -473,43 +490,16 @@ int floatCompressImpl(
   const uint32_t maxTiles = tilesFor(maxSize);
   const ZeroLayout zl((size_t)B * kNumSymbols, B, maxTiles);
   DGPU_ALLOC(zero, uint32_t, arena, zl.words);
-  const size_t zeroWords = zl.words;
   uint32_t* histTemp = zero;
   uint32_t* checksumTemp = zero + zl.checksumAt;
   uint32_t* ticket = zero + zl.ticketAt;
   uint64_t* tileDesc = (uint64_t*)(zero + zl.descAt);
-  DGPU_HIP(hipMemsetAsync(zero, 0, zeroWords * 4, stream));
+  DGPU_HIP(hipMemsetAsync(zero, 0, zl.words * 4, stream));
 
-  // exponent plane, rows 16-byte aligned (GpuFloatCompress.cuh:470-474)
-  const uint32_t compStride = roundUp(std::max(maxSize, 1u), 16u);
-  DGPU_ALLOC(comp, uint8_t, arena, (size_t)B * compStride);
-
-  if (useChecksum) {
-    // Quirk kept from the reference: size in float WORDS consumed as BYTES
-    dim3 grid(gridX(maxSize, 64 * 1024, 64), B);
-    DGPU_LAUNCH("k_checksum", stream, k_checksum, grid, dim3(256), 0, stream, in, (const uint32_t*)nullptr, checksumTemp);
-    DGPU_HIP(hipGetLastError());
-  }
-  {
-    SplitArgs s;
-    s.in = in;
-    s.out = out;
-    s.compOut = comp;
-    s.compStride = compStride;
-    s.useChecksum = useChecksum ? 1 : 0;
-    s.checksum = useChecksum ? checksumTemp : nullptr;
-    s.hist = histTemp;
-    dim3 grid(gridX(maxSize * floatWordBytes(ft), 32 * 1024, 256), B);
-    if (ft == kFloat16) launchSplitFT<kFloat16>(s, grid, stream);
-    else if (ft == kBFloat16) launchSplitFT<kBFloat16>(s, grid, stream);
-    else launchSplitFT<kFloat32>(s, grid, stream);
-    DGPU_HIP(hipGetLastError());
-  }
-  BatchView symbols = viewStride(comp, compStride, 0);
-  symbols.sizes = sz;
+  // No exponent plane in temp memory: the encoder splits the float words itself.
   rc = encodeCommon(
-      arena, stream, P, false, B, symbols, in, out, ft, maxSize, histTemp, zero, zeroWords,
-      histTemp, checksumTemp, tileDesc, ticket, maxTiles, true, outSize_dev);
+      arena, stream, P, useChecksum != 0, B, in, out, ft, maxSize, nullptr, histTemp, checksumTemp,
+      tileDesc, ticket, maxTiles, outSize_dev);
   if (tempUsed) *tempUsed = arena.requested();
   return rc;
 }
@@ -659,6 +649,14 @@ extern "C" {
 const char* dgpu_version(void) { return "dietgpu_amd 0.1 (gfx950)"; }
 const char* dgpu_last_error(void) { return g_lastError.c_str(); }
 
+#ifdef DGPU_PHASE_TIMING
+// debug builds only: point the encode kernel's phase-timing hook at a device buffer
+int dgpu_debug_set_phase_buffer(void* buf_dev) {
+  DGPU_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_phaseBuf), &buf_dev, sizeof(void*)));
+  return DGPU_OK;
+}
+#endif
+
 void dgpu_prof_enable(int on) {
   ProfState& p = prof();
   std::lock_guard<std::mutex> g(p.mu);
@@ -731,9 +729,7 @@ size_t dgpu_ans_decode_temp_bytes(uint32_t B, uint32_t maxBytes, int probBits) {
 
 size_t dgpu_float_compress_temp_bytes(uint32_t ft, uint32_t B, uint32_t maxFloats) {
   (void)ft;
-  size_t t = dgpu_ans_encode_temp_bytes(B, maxFloats);
-  t += alignUp((size_t)B * roundUp(std::max(maxFloats, 1u), 16u), kTempAlign);  // exponent plane
-  return t;
+  return dgpu_ans_encode_temp_bytes(B, maxFloats);  // no exponent plane: the split is fused into the encoder
 }
 
 size_t dgpu_float_decompress_temp_bytes(uint32_t ft, uint32_t B, uint32_t maxFloats, int probBits) {
@@ -1031,6 +1027,7 @@ int dgpu_ans_calc_weights(
   n.useChecksum = 0;
   n.checksum = nullptr;
   n.outSize = nullptr;
+  n.floatUseChecksum = 0;
   hipLaunchKernelGGL(k_normalize, dim3(numInBatch), dim3(256), 0, (hipStream_t)stream, n);
   DGPU_HIP(hipGetLastError());
   return DGPU_OK;

@@ -222,6 +222,7 @@ __device__ __forceinline__ void decodeBlock(
   uint4 pending = make_uint4(0, 0, 0, 0);
   int pendingChunk = -1;
 
+  // Generic step (partial blocks): predicated, the word read under a branch.
   auto step = [&](bool valid) -> uint32_t {
     const uint2 e = lut[state & kMask];
     if (valid) state = __umul24(e.x, state >> P) + e.y;
@@ -236,6 +237,22 @@ __device__ __forceinline__ void decodeBlock(
       const uint32_t w = *(const LdsU16*)(uintptr_t)(((idx << 1) & (kRingBytes - 1u)) | ringBase);
       state = (state << kEncodedBits) | w;
     }
+    return e.x;
+  };
+
+  // Full-block step: straight-line code, no exec-mask change and no branch.
+  // Every lane reads a ring word (the address always falls inside the ring); only
+  // lanes that need to renormalise keep it.
+  auto stepFull = [&]() -> uint32_t {
+    const uint2 e = lut[state & kMask];
+    state = __umul24(e.x, state >> P) + e.y;
+    const bool read = state < kMinState;
+    const uint64_t vote = __ballot(read);
+    const uint32_t vh = upper ? (uint32_t)(vote >> 32) : (uint32_t)vote;
+    posw -= __popc(vh);
+    const uint32_t idx = posw + __popc(vh & laneMaskLt);
+    const uint32_t w = *(const LdsU16*)(uintptr_t)(((idx << 1) & (kRingBytes - 1u)) | ringBase);
+    state = read ? ((state << kEncodedBits) | w) : state;
     return e.x;
   };
 
@@ -272,9 +289,14 @@ __device__ __forceinline__ void decodeBlock(
 #pragma unroll
     for (int j = (int)kGroupRows - 1; j >= 0; --j) {
       const uint32_t row = (uint32_t)g * kGroupRows + j;
-      const bool valid = kFull || row * 32u + hl < n;
-      const uint32_t e0 = step(valid);
-      if (valid) sink.store(row, e0, preCur[j]);
+      if (kFull) {
+        const uint32_t e0 = stepFull();
+        sink.store(row, e0, preCur[j]);
+      } else {
+        const bool valid = row * 32u + hl < n;
+        const uint32_t e0 = step(valid);
+        if (valid) sink.store(row, e0, preCur[j]);
+      }
     }
 #pragma unroll
     for (int j = 0; j < (int)kGroupRows; ++j) preCur[j] = preNext[j];

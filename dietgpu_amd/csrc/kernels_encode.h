@@ -1,21 +1,35 @@
-// rANS encode for gfx950, single pass.
+// rANS encode for gfx950, single pass, with the float split fused in.
 //
-// What it computes is the reference's ansEncodeBatchFull/Partial +
-// batchExclusivePrefixSum + ansEncodeCoalesceBatch
-// (dietgpu/ans/GpuANSEncode.cuh:49-211, 301-672); how it computes it is
-// different:
+// What it computes is the reference's splitFloat (float path) +
+// ansEncodeBatchFull/Partial + batchExclusivePrefixSum + ansEncodeCoalesceBatch
+// (dietgpu/float/GpuFloatCompress.cuh:280-365, dietgpu/ans/GpuANSEncode.cuh:
+// 49-211, 301-672); how it computes it is different:
 //
 //   * The wire format interleaves 32 rANS states per 4 KiB block.  A wave64
 //     therefore encodes TWO blocks at once: lanes 0-31 own block 2w, lanes
 //     32-63 own block 2w+1.  One 64-bit ballot per row serves both halves;
 //     each half takes its own 32-bit slice for the prefix popcount.
-//   * Each half-wave emits its u16 words into an LDS stage (no scattered 2-byte
-//     global stores, no 5248-byte-per-block scratch in HBM).
-//   * A workgroup (4 waves = 8 blocks = one "tile") publishes the padded word
-//     count of its tile and obtains its archive offset with a decoupled
-//     look-back over the preceding tiles of the same batch element, then
-//     copies the stage to its final place with 16-byte stores.  The input is
-//     read once, the archive written once; there is no coalesce pass.
+//   * Symbols reach the lanes through a 512-byte LDS ring per block (16 rows):
+//     16-byte global loads, one ds_write_b128, then a ds_read_u8 per row whose
+//     result is turned into the LDS address of the symbol's table entry right
+//     away.  Neither that nor the table lookup depends on the rANS state, so
+//     both run ahead of the dependent chain.
+//   * For the float codec the SOURCE of a chunk is the float words themselves:
+//     the lane splits its 16 words with packed byte tricks (v_perm / v_bfi /
+//     v_alignbit), stores the 16 non-compressed bytes straight into the
+//     archive and hands the 16 exponent bytes to the ring.  The exponent plane
+//     never exists in HBM (the reference writes and re-reads it).
+//   * The row step of a full block is branch-free straight-line code: lanes
+//     that do not emit store to a private scratch slot, so no exec-mask
+//     juggling or branch issue slots are spent (integer VALU ops issue at ~4
+//     cycles per wave-instruction per SIMD on this chip, LDS/VMEM instructions
+//     at 10-15: every instruction in the row counts).
+//   * Each half-wave emits its u16 words into an LDS stage.  A workgroup (4
+//     waves = 8 blocks = one "tile") publishes the padded word count of its
+//     tile and obtains its archive offset with a decoupled look-back over the
+//     preceding tiles of the same batch element, then copies the stage to its
+//     final place with 16-byte stores.  There is no scratch buffer in HBM and
+//     no coalesce pass.
 //   * Tiles are handed out by an atomic ticket in (element, tile) order, so a
 //     tile only ever waits on tiles that have already started: the look-back
 //     cannot deadlock whatever order the hardware dispatches workgroups in.
@@ -33,16 +47,13 @@ namespace dgpu {
 // Upper bound of u16 words one block can emit: per lane, 128 symbols of at
 // most P bits each plus the 16-bit start/end slack and the sub-bit rounding
 // slop of the state update => 8 * P + 1 words per lane.
-#ifdef DGPU_EXPERIMENT_STAGE_WORDS
-__host__ __device__ constexpr uint32_t encStageWords(int) { return DGPU_EXPERIMENT_STAGE_WORDS; }
-#else
 __host__ __device__ constexpr uint32_t encStageWords(int P) { return 32u * (8u * (uint32_t)P + 1u); }
-#endif
 __host__ __device__ constexpr uint32_t encLdsBytes(int P) {
   return 4096u                                   // packed symbol table
+      + 128u                                     // tile bookkeeping
       + kBlocksPerTile * encStageWords(P) * 2u   // bitstream stage per half-wave
-      + kBlocksPerTile * 512u                    // input ring, 16 rows per half-wave
-      + 128u;                                    // tile bookkeeping
+      + kBlocksPerTile * 512u                    // symbol ring, 16 rows per half-wave
+      + 512u;                                    // scratch slots of non-emitting lanes
 }
 
 constexpr uint64_t kDescAggregate = 1ull << 62;
@@ -50,15 +61,15 @@ constexpr uint64_t kDescInclusive = 2ull << 62;
 constexpr uint64_t kDescValueMask = (1ull << 62) - 1;
 
 struct EncodeArgs {
-  BatchView in;              // bytes to encode (raw input or the float comp plane)
+  BatchView in;              // raw bytes (FT == 0) or float words (FT != 0); size(b) = symbols = bytes / words
   BatchView out;             // archive base pointers
-  BatchView sizes;           // size(b) = number of symbols of element b
-  uint32_t floatType;        // != 0: ANS archive embedded in a float archive
   const uint4* encTable;     // [B][256] from k_normalize
   uint32_t maxTiles;         // tiles per element the ticket space is laid out for
   uint64_t* tileDesc;        // [B][maxTiles], zeroed before launch
   uint32_t* ticket;          // zeroed before launch
   uint32_t* outSize;         // [B] nullable
+  uint32_t useChecksum;      // float header only
+  const uint32_t* checksum;  // [B] nullable (float header only)
 };
 
 struct TileShared {
@@ -68,14 +79,190 @@ struct TileShared {
   uint32_t localOff[kBlocksPerTile];
 };
 
-template <int P, bool kFull>
+// Optional in-kernel phase timing (debug builds only: -DDGPU_PHASE_TIMING).
+// Thread 0 of every tile records s_memtime at phase boundaries into
+// g_phaseBuf[ticket * 8 + k]; tools/phase_timing.py reduces them.
+#ifdef DGPU_PHASE_TIMING
+__device__ uint64_t* g_phaseBuf = nullptr;
+#define DGPU_PHASE(k)                                                             \
+  do {                                                                            \
+    if (threadIdx.x == 0 && g_phaseBuf) g_phaseBuf[(size_t)phaseSlot * 8 + (k)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define DGPU_PHASE(k) do {} while (0)
+#endif
+
+typedef __attribute__((address_space(3))) uint16_t LdsU16e;
+typedef uint32_t u32x4e __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4e LdsU4e;
+
+// table entry at an absolute LDS address
+__device__ __forceinline__ uint4 ldsTableEntry(uint32_t addr) {
+  const u32x4e v = *(const LdsU4e*)(uintptr_t)addr;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// ---------------------------------------------------------------------------
+// Chunk sources.  A chunk is 16 rows of one block = 512 symbols; lane hl of the
+// half-wave owns symbols [16 hl, 16 hl + 16) of the chunk when loading.
+//   load(c)    : issue the global loads of chunk c (kept in registers)
+//   consume(r) : turn them into the 16 symbol bytes for the ring; the float
+//                sources also store the non-compressed bytes into the archive
+//   symbolAt(i): scalar path for partial blocks / unaligned inputs
+template <uint32_t FT>
+struct ChunkSource;
+
+template <>
+struct ChunkSource<0> {  // raw bytes: the symbols are the input
+  struct Raw { uint4 v; };
+  const uint8_t* in;  // this half's block
+  __device__ __forceinline__ void init(const uint8_t* elemIn, uint8_t*, uint32_t, uint32_t block) {
+    in = elemIn + (size_t)block * kBlockSize;
+  }
+  __device__ __forceinline__ Raw load(uint32_t c, uint32_t hl) const {
+    Raw r;
+    r.v = ((const uint4*)in)[c * 32u + hl];
+    return r;
+  }
+  __device__ __forceinline__ uint4 consume(const Raw& r, uint32_t, uint32_t) const { return r.v; }
+  __device__ __forceinline__ uint32_t symbolAt(uint32_t i) const { return in[i]; }
+};
+
+// v_perm_b32 selectors: {lo.b0, lo.b2, hi.b0, hi.b2} and {lo.b1, lo.b3, hi.b1, hi.b3}
+__device__ __forceinline__ uint32_t packBytes02(uint32_t hi, uint32_t lo) { return __builtin_amdgcn_perm(hi, lo, 0x06040200u); }
+__device__ __forceinline__ uint32_t packBytes13(uint32_t hi, uint32_t lo) { return __builtin_amdgcn_perm(hi, lo, 0x07050301u); }
+// (mask & a) | (~mask & b)
+__device__ __forceinline__ uint32_t bitSelect(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+
+template <uint32_t FT>  // kFloat16 / kBFloat16: 2-byte words, 1 comp byte + 1 non-comp byte
+struct ChunkSource16 {
+  struct Raw { uint4 a, b; };
+  const uint16_t* in;  // this half's block (4096 words)
+  uint8_t* nc;         // this half's block of the non-comp plane
+  __device__ __forceinline__ void init(const uint8_t* elemIn, uint8_t* archive, uint32_t, uint32_t block) {
+    in = (const uint16_t*)elemIn + (size_t)block * kBlockSize;
+    nc = archive + 16u + (size_t)block * kBlockSize;
+  }
+  __device__ __forceinline__ Raw load(uint32_t c, uint32_t hl) const {
+    const uint4* p = (const uint4*)(in + c * 512u + hl * 16u);
+    Raw r;
+    r.a = p[0];
+    r.b = p[1];
+    return r;
+  }
+  // FloatTypeInfo<FT>::split (GpuFloatUtils.cuh:111-115, 141-147) on packed pairs
+  __device__ __forceinline__ uint4 consume(const Raw& r, uint32_t c, uint32_t hl) const {
+    const uint32_t x[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w};
+    uint32_t comp[4], rest[4];
+    if (FT == kFloat16) {
+      // comp = w >> 8 (bytes 1, 3 of each dword), nonComp = w & 0xff (bytes 0, 2)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        comp[j] = packBytes13(x[2 * j + 1], x[2 * j]);
+        rest[j] = packBytes02(x[2 * j + 1], x[2 * j]);
+      }
+    } else {
+      // bf16: comp = bits 14..7; nonComp = mantissa7 << 1 | sign, i.e. each
+      // 16-bit half rotated left by one, low byte
+      uint32_t t[8], q[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        t[j] = x[j] >> 7;                                         // comp in bytes 0 and 2
+        q[j] = bitSelect(0xfffefffeu, x[j] << 1, x[j] >> 15);     // non-comp in bytes 0 and 2 (v_bfi)
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        comp[j] = packBytes02(t[2 * j + 1], t[2 * j]);
+        rest[j] = packBytes02(q[2 * j + 1], q[2 * j]);
+      }
+    }
+    ((uint4*)(nc + c * 512u))[hl] = make_uint4(rest[0], rest[1], rest[2], rest[3]);
+    return make_uint4(comp[0], comp[1], comp[2], comp[3]);
+  }
+  __device__ __forceinline__ uint32_t symbolAt(uint32_t i) const {
+    const uint32_t w = in[i];
+    uint32_t c, r;
+    if (FT == kFloat16) {
+      c = w >> 8;
+      r = w & 0xffu;
+    } else {
+      c = (w >> 7) & 0xffu;
+      r = ((w << 1) & 0xfeu) | (w >> 15);
+    }
+    nc[i] = (uint8_t)r;
+    return c;
+  }
+};
+template <>
+struct ChunkSource<kFloat16> : ChunkSource16<kFloat16> {};
+template <>
+struct ChunkSource<kBFloat16> : ChunkSource16<kBFloat16> {};
+
+template <>
+struct ChunkSource<kFloat32> {  // 4-byte words: comp byte + 24 non-comp bits (u16 plane, then u8 plane)
+  struct Raw { uint4 v[4]; };
+  const uint32_t* in;
+  uint16_t* nc2;
+  uint8_t* nc1;
+  __device__ __forceinline__ void init(const uint8_t* elemIn, uint8_t* archive, uint32_t size, uint32_t block) {
+    in = (const uint32_t*)elemIn + (size_t)block * kBlockSize;
+    nc2 = (uint16_t*)(archive + 16u) + (size_t)block * kBlockSize;
+    nc1 = archive + 16u + 2u * (size_t)roundUp(size, 8u) + (size_t)block * kBlockSize;
+  }
+  __device__ __forceinline__ Raw load(uint32_t c, uint32_t hl) const {
+    const uint4* p = (const uint4*)(in + c * 512u + hl * 16u);
+    Raw r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r.v[j] = p[j];
+    return r;
+  }
+  // FloatTypeInfo<kFloat32>::split (GpuFloatUtils.cuh:181-185): v = rotl(w, 1)
+  __device__ __forceinline__ uint4 consume(const Raw& r, uint32_t c, uint32_t hl) const {
+    uint32_t v[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[4 * j + 0] = __builtin_amdgcn_alignbit(r.v[j].x, r.v[j].x, 31);
+      v[4 * j + 1] = __builtin_amdgcn_alignbit(r.v[j].y, r.v[j].y, 31);
+      v[4 * j + 2] = __builtin_amdgcn_alignbit(r.v[j].z, r.v[j].z, 31);
+      v[4 * j + 3] = __builtin_amdgcn_alignbit(r.v[j].w, r.v[j].w, 31);
+    }
+    uint32_t comp[4], hi[4], lo[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // bytes 2 (high non-comp byte) and 3 (comp) of four words -> one dword each
+      const uint32_t a = __builtin_amdgcn_perm(v[4 * j + 1], v[4 * j + 0], 0x07030602u);  // {v0.b2, v1.b2, v0.b3, v1.b3}
+      const uint32_t b = __builtin_amdgcn_perm(v[4 * j + 3], v[4 * j + 2], 0x07030602u);
+      hi[j] = __builtin_amdgcn_perm(b, a, 0x05040100u);    // {a.b0, a.b1, b.b0, b.b1}
+      comp[j] = __builtin_amdgcn_perm(b, a, 0x07060302u);  // {a.b2, a.b3, b.b2, b.b3}
+      lo[2 * j + 0] = __builtin_amdgcn_perm(v[4 * j + 1], v[4 * j + 0], 0x05040100u);  // low 16 bits of two words
+      lo[2 * j + 1] = __builtin_amdgcn_perm(v[4 * j + 3], v[4 * j + 2], 0x05040100u);
+    }
+    uint4* p2 = (uint4*)(nc2 + c * 512u + hl * 16u);
+    p2[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    p2[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+    ((uint4*)(nc1 + c * 512u))[hl] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    return make_uint4(comp[0], comp[1], comp[2], comp[3]);
+  }
+  __device__ __forceinline__ uint32_t symbolAt(uint32_t i) const {
+    const uint32_t w = in[i];
+    const uint32_t v = (w << 1) | (w >> 31);
+    nc2[i] = (uint16_t)(v & 0xffffu);
+    nc1[i] = (uint8_t)((v >> 16) & 0xffu);
+    return v >> 24;
+  }
+};
+
+// ---------------------------------------------------------------------------
+template <int P, uint32_t FT, bool kFull>
 __device__ __forceinline__ uint32_t encodeRows(
-    const uint8_t* __restrict__ inBlock,  // this half's block (global)
+    const ChunkSource<FT>& src,
     uint32_t n,                           // symbols in this half's block (0 = idle half)
     uint32_t maxRows,                     // wave-uniform row count
     const uint4* __restrict__ table,      // LDS
-    uint16_t* __restrict__ stage,         // LDS, this half's stage
-    uint8_t* __restrict__ ring,           // LDS, this half's 512-byte input ring
+    uint32_t tableLds,                    // LDS address of `table`
+    uint32_t stageBase,                   // LDS address of this half's word stage
+    uint32_t dummyAddr,                   // LDS address of this lane's scratch slot
+    uint8_t* __restrict__ ring,           // LDS, this half's 512-byte symbol ring
     uint32_t hl,
     bool upper,
     uint32_t& stateOut) {
@@ -83,14 +270,17 @@ __device__ __forceinline__ uint32_t encodeRows(
   uint32_t state = kStartState;
   uint32_t outOff = 0;
 
+  // Generic step (partial blocks): predicated, emission under a branch.
   auto step = [&](const uint4 e, bool valid) {
     const bool write = valid && (state >= e.x);
     const uint64_t vote = __ballot(write);
     const uint32_t vh = upper ? (uint32_t)(vote >> 32) : (uint32_t)vote;
     if (write) {
-      stage[outOff + __popc(vh & laneMaskLt)] = (uint16_t)(state & 0xffffu);
-      state >>= kEncodedBits;
+      // emitters of a row write in ascending lane order (ds_write_b16 keeps the low half)
+      const uint32_t idx = outOff + __popc(vh & laneMaskLt);
+      *(LdsU16e*)(uintptr_t)(stageBase + 2u * idx) = (uint16_t)state;
     }
+    state = write ? (state >> kEncodedBits) : state;
     // state = ((state / pdf) << P) + state % pdf + cdf
     //       = state + cdf + (state / pdf) * (2^P - pdf)
     const uint32_t t = __umulhi(state, e.y);
@@ -100,31 +290,47 @@ __device__ __forceinline__ uint32_t encodeRows(
     outOff += __popc(vh);
   };
 
+  // Full-block step: straight-line code, no exec-mask change and no branch.
+  auto stepFull = [&](const uint4 e) {
+    const bool write = state >= e.x;
+    const uint64_t vote = __ballot(write);
+    const uint32_t vh = upper ? (uint32_t)(vote >> 32) : (uint32_t)vote;
+    const uint32_t idx = outOff + __popc(vh & laneMaskLt);
+    const uint32_t addr = write ? stageBase + 2u * idx : dummyAddr;
+    *(LdsU16e*)(uintptr_t)addr = (uint16_t)state;
+    state = write ? (state >> kEncodedBits) : state;
+    const uint32_t t = __umulhi(state, e.y);
+    const uint32_t div = (t + state) >> (e.w >> 24);
+    state = __umul24(div, e.w) + state + e.z;
+    outOff += __popc(vh);
+  };
+
   if (kFull) {
     // 8 chunks of 16 rows; chunk c+1 is in flight in registers while chunk c is
     // consumed from the LDS ring (same wave writes and reads it: LDS ops of one
-    // wave execute in order, no barrier needed).  Neither the symbol fetch nor
-    // the table lookup depends on the rANS state, so both are issued ahead of
-    // the dependent chain: all 16 symbols at the chunk start, table entries
-    // kAhead rows ahead.
+    // wave execute in order, no barrier needed).
     constexpr int kAhead = 4;
-    const uint4* src = (const uint4*)inBlock + hl;
-    uint4 cur = src[0];
+    typename ChunkSource<FT>::Raw cur = src.load(0, hl);
 #pragma unroll 1
     for (uint32_t c = 0; c < kRowsPerBlock / 16; ++c) {
-      *(uint4*)(ring + hl * 16u) = cur;
-      if (c + 1 < kRowsPerBlock / 16) cur = src[(c + 1) * 32u];
-      uint32_t sym[16];
+      const uint4 symbols = src.consume(cur, c, hl);
+      *(uint4*)(ring + hl * 16u) = symbols;
+      if (c + 1 < kRowsPerBlock / 16) cur = src.load(c + 1, hl);
+      // LDS addresses of the 16 table entries (table + sym * 16), formed right at the load
+      uint32_t toff[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sym[r] = ring[r * 32 + hl];
+      for (int r = 0; r < 16; ++r) {
+        toff[r] = tableLds + ((uint32_t)ring[r * 32 + hl] << 4);
+        asm volatile("" : "+v"(toff[r]));  // keep the scaled address; do not re-derive it (with a mask) at the use
+      }
       uint4 e[kAhead];
 #pragma unroll
-      for (int r = 0; r < kAhead; ++r) e[r] = table[sym[r]];
+      for (int r = 0; r < kAhead; ++r) e[r] = ldsTableEntry(toff[r]);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const uint4 cur_e = e[r % kAhead];
-        if (r + kAhead < 16) e[r % kAhead] = table[sym[r + kAhead]];
-        step(cur_e, true);
+        if (r + kAhead < 16) e[r % kAhead] = ldsTableEntry(toff[r + kAhead]);
+        stepFull(cur_e);
       }
     }
   } else {
@@ -132,7 +338,7 @@ __device__ __forceinline__ uint32_t encodeRows(
     for (uint32_t row = 0; row < maxRows; ++row) {
       const uint32_t i = row * 32u + hl;
       const bool valid = i < n;
-      const uint32_t sym = valid ? inBlock[i] : 0u;
+      const uint32_t sym = valid ? src.symbolAt(i) : 0u;
       step(table[sym], valid);
     }
   }
@@ -140,7 +346,7 @@ __device__ __forceinline__ uint32_t encodeRows(
   return outOff;
 }
 
-template <int P>
+template <int P, uint32_t FT>
 __global__ __launch_bounds__(256) void k_ans_encode(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   // bookkeeping sits BELOW the stages so that a stage overrun (only possible
@@ -163,19 +369,47 @@ __global__ __launch_bounds__(256) void k_ans_encode(EncodeArgs a) {
   }
   __syncthreads();
   const uint32_t ticket = sh->ticket;
+#ifdef DGPU_PHASE_TIMING
+  const uint32_t phaseSlot = ticket;
+#endif
+  DGPU_PHASE(0);
   const uint32_t b = ticket / a.maxTiles;
   const uint32_t tile = ticket - b * a.maxTiles;
 
-  const uint32_t size = a.sizes.size(b);
+  const uint32_t size = a.in.size(b);
   const uint32_t nb = divUp(size, kBlockSize);
   const uint32_t numTiles = divUp(nb, kBlocksPerTile);
   if (tile >= numTiles) return;  // uniform for the workgroup
 
   sTable[tid] = a.encTable[b * kNumSymbols + tid];
   __syncthreads();
+  DGPU_PHASE(1);
 
   const uint8_t* in = a.in.ptr(b);
-  uint8_t* ans = a.out.ptr(b) + ansOffsetInArchive(a.floatType, size);
+  uint8_t* archive = a.out.ptr(b);
+  uint8_t* ans = archive + ansOffsetInArchive(FT, size);
+
+  if (FT != 0 && tile == 0) {
+    // GpuFloatHeader (GpuFloatCompress.cuh:325-337) and the zero padding of the
+    // non-comp plane(s) up to 16 bytes
+    if (tid == 0) {
+      FloatHeader h;
+      h.magicAndVersion = (kFloatMagic << 16) | kFloatVersion;
+      h.size = size;
+      h.options = FT | (a.useChecksum ? 0x10u : 0u);
+      h.checksum = (a.useChecksum && a.checksum) ? a.checksum[b] : 0u;
+      *(FloatHeader*)archive = h;
+    }
+    if (FT == kFloat32) {
+      uint16_t* nc2 = (uint16_t*)(archive + 16u);
+      uint8_t* nc1 = archive + 16u + 2u * (size_t)roundUp(size, 8u);
+      if (size + tid < roundUp(size, 8u)) nc2[size + tid] = 0;
+      if (size + tid < roundUp(size, 16u)) nc1[size + tid] = 0;
+    } else {
+      uint8_t* nc = archive + 16u;
+      if (size + tid < roundUp(size, 16u)) nc[size + tid] = 0;
+    }
+  }
 
   const uint32_t block = tile * kBlocksPerTile + hw;
   const bool haveBlock = block < nb;
@@ -184,17 +418,23 @@ __global__ __launch_bounds__(256) void k_ans_encode(EncodeArgs a) {
     const uint32_t begin = block * kBlockSize;
     n = size - begin < kBlockSize ? size - begin : kBlockSize;
   }
-  // wave-uniform: are both halves full blocks?
+  // wave-uniform: are both halves full blocks (and the input vector-aligned)?
   const uint32_t firstBlockOfWave = tile * kBlocksPerTile + wave * 2u;
   const bool waveFull = (uint64_t)(firstBlockOfWave + 2u) * kBlockSize <= (uint64_t)size &&
       (((uintptr_t)in & 15u) == 0);
 
+  ChunkSource<FT> src;
+  src.init(in, archive, size, block);
+
   uint16_t* stage = sStage + hw * encStageWords(P);
+  const uint32_t stageLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)stage;
+  const uint32_t tableLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)sTable;
+  // per-lane scratch slot for non-emitting lanes (512 bytes after the rings)
+  const uint32_t dummyLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(sRing + kBlocksPerTile * 512u) + tid * 2u;
   uint32_t state;
   uint32_t words;
-  const uint8_t* inBlock = in + (size_t)block * kBlockSize;
   if (waveFull) {
-    words = encodeRows<P, true>(inBlock, n, kRowsPerBlock, sTable, stage, sRing + hw * 512u, hl, upper, state);
+    words = encodeRows<P, FT, true>(src, n, kRowsPerBlock, sTable, tableLds, stageLds, dummyLds, sRing + hw * 512u, hl, upper, state);
   } else {
     // rows needed by the larger of the two halves (uniform)
     uint32_t nA = 0;
@@ -202,9 +442,10 @@ __global__ __launch_bounds__(256) void k_ans_encode(EncodeArgs a) {
       uint32_t beginA = firstBlockOfWave * kBlockSize;
       nA = size - beginA < kBlockSize ? size - beginA : kBlockSize;  // first half is never smaller than the second
     }
-    words = encodeRows<P, false>(inBlock, n, divUp(nA, 32u), sTable, stage, nullptr, hl, upper, state);
+    words = encodeRows<P, FT, false>(src, n, divUp(nA, 32u), sTable, tableLds, stageLds, dummyLds, nullptr, hl, upper, state);
   }
 
+  DGPU_PHASE(2);
   if (haveBlock) {
     // final lane states, 128 contiguous bytes per block (GpuANSEncode.cuh:207, :584-590)
     ((uint32_t*)(ans + ansStatesOffset()))[block * 32u + hl] = state;
@@ -215,6 +456,7 @@ __global__ __launch_bounds__(256) void k_ans_encode(EncodeArgs a) {
   words = words < encStageWords(P) ? words : encStageWords(P);
   if (hl == 0) sh->words[hw] = haveBlock ? words : 0u;
   __syncthreads();
+  DGPU_PHASE(3);
 
   if (wave == 0) {
     // local exclusive scan of the padded sizes of the tile's 8 blocks
@@ -258,7 +500,7 @@ __global__ __launch_bounds__(256) void k_ans_encode(EncodeArgs a) {
         // complete the header (GpuANSEncode.cuh:533-566)
         ((AnsHeader*)ans)->totalCompressedWords = inclusive;
         if (a.outSize) {
-          a.outSize[b] = ansOffsetInArchive(a.floatType, size) + ansOverhead(nb) + 2u * inclusive;
+          a.outSize[b] = ansOffsetInArchive(FT, size) + ansOverhead(nb) + 2u * inclusive;
         }
       }
     }
@@ -275,13 +517,68 @@ __global__ __launch_bounds__(256) void k_ans_encode(EncodeArgs a) {
     }
   }
   __syncthreads();
+  DGPU_PHASE(4);
 
   if (haveBlock) {
     const uint32_t vecs = roundUp(words, kBlockAlignWords) / kBlockAlignWords;
-    const uint4* src = (const uint4*)stage;
+    const uint4* s4 = (const uint4*)stage;
     uint4* dst = (uint4*)(ans + ansOverhead(nb) + 2u * (size_t)(sh->tileBase + sh->localOff[hw]));
-    for (uint32_t i = hl; i < vecs; i += 32u) dst[i] = src[i];
+    for (uint32_t i = hl; i < vecs; i += 32u) dst[i] = s4[i];
   }
+  DGPU_PHASE(5);
+}
+
+// ---------------------------------------------------------------------------
+// Exponent histogram of float inputs: a read-only pass over the float words
+// (the histogram the reference fuses into splitFloat,
+// GpuFloatCompress.cuh:144, 352-364).  grid = (xBlocks, B), 256 threads;
+// hist must be zeroed first.
+template <uint32_t FT>
+__global__ __launch_bounds__(256) void k_float_histogram(BatchView in, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t bins[kHistBlockWords];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t b = blockIdx.y;
+  histZero(bins, tid);
+  __syncthreads();
+  uint32_t* myBins = histMine(bins, tid);
+
+  const uint32_t n = in.size(b);
+  const uint8_t* inBytes = in.ptr(b);
+  const bool aligned = (((uintptr_t)inBytes) & 15u) == 0;
+
+  if (FT == kFloat32) {
+    const uint32_t* w = (const uint32_t*)inBytes;
+    const uint32_t numVec = aligned ? n / 4u : 0u;
+    for (uint32_t v = blockIdx.x * 256u + tid; v < numVec; v += gridDim.x * 256u) {
+      const uint4 x = ((const uint4*)w)[v];
+      atomicAdd(&myBins[(x.x >> 23) & 0xffu], 1u);
+      atomicAdd(&myBins[(x.y >> 23) & 0xffu], 1u);
+      atomicAdd(&myBins[(x.z >> 23) & 0xffu], 1u);
+      atomicAdd(&myBins[(x.w >> 23) & 0xffu], 1u);
+    }
+    for (uint32_t i = numVec * 4u + blockIdx.x * 256u + tid; i < n; i += gridDim.x * 256u) {
+      atomicAdd(&myBins[(w[i] >> 23) & 0xffu], 1u);
+    }
+  } else {
+    const uint16_t* w = (const uint16_t*)inBytes;
+    constexpr uint32_t kShift = FT == kFloat16 ? 8u : 7u;
+    const uint32_t numVec = aligned ? n / 8u : 0u;
+    for (uint32_t v = blockIdx.x * 256u + tid; v < numVec; v += gridDim.x * 256u) {
+      const uint4 x = ((const uint4*)w)[v];
+      const uint32_t xw[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        atomicAdd(&myBins[(xw[j] >> kShift) & 0xffu], 1u);
+        atomicAdd(&myBins[(xw[j] >> (16u + kShift)) & 0xffu], 1u);
+      }
+    }
+    for (uint32_t i = numVec * 8u + blockIdx.x * 256u + tid; i < n; i += gridDim.x * 256u) {
+      atomicAdd(&myBins[((uint32_t)w[i] >> kShift) & 0xffu], 1u);
+    }
+  }
+  __syncthreads();
+  const uint32_t sum = histFold(bins, tid);
+  if (sum) atomicAdd(&hist[b * kNumSymbols + tid], sum);
 }
 
 }  // namespace dgpu

@@ -175,6 +175,7 @@ struct NormalizeArgs {
   uint32_t useChecksum;
   const uint32_t* checksum;  // [B] nullable
   uint32_t* outSize;         // [B] nullable
+  uint32_t floatUseChecksum; // float archives: checksum flag for the header of an EMPTY element
 };
 
 __global__ __launch_bounds__(256) void k_normalize(NormalizeArgs a) {
@@ -291,8 +292,17 @@ __global__ __launch_bounds__(256) void k_normalize(NormalizeArgs a) {
       h.unused0 = 0;
       h.unused1 = 0;
       *(AnsHeader*)ans = h;
-      if (nb == 0 && a.outSize) {
-        a.outSize[b] = ansOffsetInArchive(a.floatType, total) + ansOverhead(0);
+      if (nb == 0) {
+        // empty element: no encode tile will run for it
+        if (a.outSize) a.outSize[b] = ansOffsetInArchive(a.floatType, total) + ansOverhead(0);
+        if (a.floatType) {
+          FloatHeader fh;
+          fh.magicAndVersion = (kFloatMagic << 16) | kFloatVersion;
+          fh.size = 0;
+          fh.options = a.floatType | (a.floatUseChecksum ? 0x10u : 0u);
+          fh.checksum = 0;
+          *(FloatHeader*)a.out.ptr(b) = fh;
+        }
       }
     }
   }

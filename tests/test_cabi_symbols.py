@@ -39,9 +39,9 @@ def test_size_queries_match_oracle():
             assert L.dgpu_float_max_compressed_size(ft, n) == O.float_max_compressed_size(ft, n)
     assert L.dgpu_ans_max_compressed_size(1 << 20) == 1868320
     assert L.dgpu_float_max_compressed_size(2, 524288) == 1737264
-    # temp-size queries are monotone and cover the 256 x 1 MiB configs without the 328 MiB scratch
-    t = L.dgpu_float_compress_temp_bytes(2, 256, 524288)
-    assert 128 * 1024 * 1024 < t < 160 * 1024 * 1024
+    # temp memory of the 256 x 1 MiB configs: a few MiB (tables, tile descriptors), not the
+    # reference's 328 MiB block scratch + 128 MiB exponent plane
+    assert L.dgpu_float_compress_temp_bytes(2, 256, 524288) < 4 * 1024 * 1024
     assert L.dgpu_ans_encode_temp_bytes(256, 1 << 20) < 4 * 1024 * 1024
 
 

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Debug tool: per-phase cycle counts inside k_ans_encode (needs a -DDGPU_PHASE_TIMING build).
+
+Builds a debug library next to the product one, runs the bf16 bench workload
+once and prints the mean s_memtime delta of each phase per tile."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+DBG = "/tmp/libdietgpu_amd_dbg.so"
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                       "-DDGPU_PHASE_TIMING", "-o", DBG, os.path.join(ROOT, "dietgpu_amd/csrc/capi.hip")])
+import dietgpu_amd.build as b
+b.LIB_PATH = DBG
+import dietgpu_amd._lib as L
+L.LIB_PATH = DBG
+import dietgpu_amd as dg
+import bench
+
+lib = C.CDLL(DBG)
+dev = torch.device("cuda:0")
+wl = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+data, ft, _, P, desc = bench.make_workload(wl, 256, 1234, dev)
+codec = bench.Codec(dg, data, ft, P)
+codec.lib = dg.lib()
+for _ in range(3):
+    codec.step()
+torch.cuda.synchronize()
+ntiles = 256 * 64
+buf = torch.zeros((ntiles, 8), dtype=torch.int64, device=dev)
+assert lib.dgpu_debug_set_phase_buffer(C.c_void_p(buf.data_ptr())) == 0
+codec.encode()
+torch.cuda.synchronize()
+t = buf.cpu().numpy()
+t = t[t[:, 0] != 0]
+names = ["ticket->table", "rows", "states+sync", "lookback", "copy"]
+print(f"{wl}: {t.shape[0]} tiles")
+for k, n in enumerate(names):
+    d = (t[:, k + 1] - t[:, k]).astype(np.float64)
+    print(f"  {n:16s} mean {d.mean():9.0f}  p50 {np.median(d):9.0f}  p95 {np.percentile(d, 95):9.0f} cycles (s_memtime @100MHz? ticks)")
+tot = (t[:, 5] - t[:, 0]).astype(np.float64)
+print(f"  {'total':16s} mean {tot.mean():9.0f}")
+print("  span of kernel (max end - min start):", int(t[:, 5].max() - t[:, 0].min()))
