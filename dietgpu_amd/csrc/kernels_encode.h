@@ -546,35 +546,45 @@ __global__ __launch_bounds__(256) void k_float_histogram(BatchView in, uint32_t*
   const uint8_t* inBytes = in.ptr(b);
   const bool aligned = (((uintptr_t)inBytes) & 15u) == 0;
 
-  if (FT == kFloat32) {
-    const uint32_t* w = (const uint32_t*)inBytes;
-    const uint32_t numVec = aligned ? n / 4u : 0u;
-    for (uint32_t v = blockIdx.x * 256u + tid; v < numVec; v += gridDim.x * 256u) {
-      const uint4 x = ((const uint4*)w)[v];
-      atomicAdd(&myBins[(x.x >> 23) & 0xffu], 1u);
-      atomicAdd(&myBins[(x.y >> 23) & 0xffu], 1u);
-      atomicAdd(&myBins[(x.z >> 23) & 0xffu], 1u);
-      atomicAdd(&myBins[(x.w >> 23) & 0xffu], 1u);
-    }
-    for (uint32_t i = numVec * 4u + blockIdx.x * 256u + tid; i < n; i += gridDim.x * 256u) {
-      atomicAdd(&myBins[(w[i] >> 23) & 0xffu], 1u);
-    }
-  } else {
-    const uint16_t* w = (const uint16_t*)inBytes;
-    constexpr uint32_t kShift = FT == kFloat16 ? 8u : 7u;
-    const uint32_t numVec = aligned ? n / 8u : 0u;
-    for (uint32_t v = blockIdx.x * 256u + tid; v < numVec; v += gridDim.x * 256u) {
-      const uint4 x = ((const uint4*)w)[v];
+  constexpr uint32_t kWordsPerVec = FT == kFloat32 ? 4u : 8u;
+  const uint32_t numVec = aligned ? n / kWordsPerVec : 0u;
+  const uint32_t stride = gridDim.x * 256u;
+  const uint4* pv = (const uint4*)inBytes;
+
+  auto addVec = [&](const uint4& x) {
+    if (FT == kFloat32) {
+      histAdd(myBins, (x.x >> 23) & 0xffu);
+      histAdd(myBins, (x.y >> 23) & 0xffu);
+      histAdd(myBins, (x.z >> 23) & 0xffu);
+      histAdd(myBins, (x.w >> 23) & 0xffu);
+    } else {
+      constexpr uint32_t kShift = FT == kFloat16 ? 8u : 7u;
       const uint32_t xw[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        atomicAdd(&myBins[(xw[j] >> kShift) & 0xffu], 1u);
-        atomicAdd(&myBins[(xw[j] >> (16u + kShift)) & 0xffu], 1u);
+        histAdd(myBins, (xw[j] >> kShift) & 0xffu);
+        histAdd(myBins, (xw[j] >> (16u + kShift)) & 0xffu);
       }
     }
-    for (uint32_t i = numVec * 8u + blockIdx.x * 256u + tid; i < n; i += gridDim.x * 256u) {
-      atomicAdd(&myBins[((uint32_t)w[i] >> kShift) & 0xffu], 1u);
-    }
+  };
+
+  // four 16-byte loads in flight per lane (the kernel is HBM-latency bound otherwise)
+  uint32_t v = blockIdx.x * 256u + tid;
+  for (; v + 3u * stride < numVec; v += 4u * stride) {
+    const uint4 x0 = pv[v], x1 = pv[v + stride], x2 = pv[v + 2u * stride], x3 = pv[v + 3u * stride];
+    addVec(x0);
+    addVec(x1);
+    addVec(x2);
+    addVec(x3);
+  }
+  for (; v < numVec; v += stride) addVec(pv[v]);
+
+  // tail (and the whole element when the input is not 16-byte aligned)
+  for (uint32_t i = numVec * kWordsPerVec + blockIdx.x * 256u + tid; i < n; i += stride) {
+    uint32_t c;
+    if (FT == kFloat32) c = (((const uint32_t*)inBytes)[i] >> 23) & 0xffu;
+    else c = ((uint32_t)((const uint16_t*)inBytes)[i] >> (FT == kFloat16 ? 8u : 7u)) & 0xffu;
+    histAdd(myBins, c);
   }
   __syncthreads();
   const uint32_t sum = histFold(bins, tid);

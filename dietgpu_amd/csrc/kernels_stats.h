@@ -33,39 +33,46 @@ __device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v, uint32_t lane)
 
 // ---------------------------------------------------------------------------
 // Histogram bins in LDS.  Entropy-coder inputs are skewed (one exponent value
-// can be a third of the data), and ds_add_u32 serialises lanes that hit the
-// same address, so every wavefront keeps kHistCopies private copies of the 256
-// bins and lane l adds into copy l % kHistCopies: a hot symbol's ~20 lanes per
-// instruction spread over 8 addresses.  Copy stride is 257 words so that the
-// same bin of different copies falls into different LDS banks
-// (bank = (copy + bin) % 32).
-constexpr uint32_t kHistCopies = 8;
-constexpr uint32_t kHistCopyStride = kNumSymbols + 1;
-constexpr uint32_t kHistWaveWords = kHistCopies * kHistCopyStride;
-constexpr uint32_t kHistBlockWords = 4 * kHistWaveWords;  // 4 wavefronts per workgroup
+// can be a third of the data) and ds_add_u32 serialises lanes of one
+// instruction that hit the same address or bank, which made a per-wave
+// privatised layout run at ~2 lane-updates per clock per CU.  Layout used
+// instead: bin-major with kHistSlots lane slots per bin,
+//     word(bin, lane) = bin * 16 + (lane & 15),  bank = 16 * (bin & 1) + (lane & 15)
+// so lanes with different slots can never collide and the two lanes that share
+// a slot within a 32-lane LDS pass (l and l + 16) collide at most 2-way.  The
+// four wavefronts of a workgroup share the same 16 KiB (ds_add is atomic;
+// different waves are different instructions and merely interleave).
+constexpr uint32_t kHistSlots = 16;
+constexpr uint32_t kHistBlockWords = kNumSymbols * kHistSlots;  // 16 KiB
 
 __device__ __forceinline__ void histZero(uint32_t* bins, uint32_t tid) {
-  for (uint32_t i = tid; i < kHistBlockWords; i += 256u) bins[i] = 0;
+  for (uint32_t i = tid; i < kHistBlockWords / 4u; i += 256u) ((uint4*)bins)[i] = make_uint4(0, 0, 0, 0);
 }
+// this lane's slot column; bin c lives at mine[c * kHistSlots]
 __device__ __forceinline__ uint32_t* histMine(uint32_t* bins, uint32_t tid) {
-  return bins + (tid >> 6) * kHistWaveWords + (tid & (kHistCopies - 1u)) * kHistCopyStride;
+  return bins + (tid & (kHistSlots - 1u));
 }
-// total of bin `tid` over all copies of all wavefronts
+__device__ __forceinline__ void histAdd(uint32_t* mine, uint32_t c) { atomicAdd(&mine[c * kHistSlots], 1u); }
+// total of bin `tid` over all slots
 __device__ __forceinline__ uint32_t histFold(const uint32_t* bins, uint32_t tid) {
+  const uint4* p = (const uint4*)(bins + tid * kHistSlots);
   uint32_t sum = 0;
 #pragma unroll
-  for (uint32_t c = 0; c < 4 * kHistCopies; ++c) sum += bins[c * kHistCopyStride + tid];
+  for (uint32_t k = 0; k < kHistSlots / 4u; ++k) {
+    const uint4 v = p[k];
+    sum += v.x + v.y + v.z + v.w;
+  }
   return sum;
 }
 
 // Histogram kernel: 16-byte loads with a byte-wise head/tail so any start
 // alignment works (the reference test uses stride size+11,
 // ANSStatisticsTest.cu:52-57).  grid = (xBlocks, B), 256 threads.
-__device__ __forceinline__ void histAdd4(uint32_t* bins, uint32_t x) {
-  atomicAdd(&bins[x & 0xff], 1u);
-  atomicAdd(&bins[(x >> 8) & 0xff], 1u);
-  atomicAdd(&bins[(x >> 16) & 0xff], 1u);
-  atomicAdd(&bins[x >> 24], 1u);
+__device__ __forceinline__ void histAdd4(uint32_t* mine, uint32_t x) {
+  histAdd(mine, x & 0xff);
+  histAdd(mine, (x >> 8) & 0xff);
+  histAdd(mine, (x >> 16) & 0xff);
+  histAdd(mine, x >> 24);
 }
 
 __global__ __launch_bounds__(256) void k_histogram(BatchView in, uint32_t* __restrict__ hist) {
@@ -86,10 +93,20 @@ __global__ __launch_bounds__(256) void k_histogram(BatchView in, uint32_t* __res
   const uint32_t numVec = remaining / 16u;
   const uint4* pv = (const uint4*)(p + head);
 
-  if (blockIdx.x == 0 && tid < head) atomicAdd(&myBins[p[tid]], 1u);
+  if (blockIdx.x == 0 && tid < head) histAdd(myBins, p[tid]);
 
-  for (uint32_t i = blockIdx.x * 256u + tid; i < numVec; i += gridDim.x * 256u) {
-    uint4 v = pv[i];
+  // four 16-byte loads in flight per lane (the kernel is HBM-latency bound otherwise)
+  const uint32_t stride = gridDim.x * 256u;
+  uint32_t i = blockIdx.x * 256u + tid;
+  for (; i + 3u * stride < numVec; i += 4u * stride) {
+    const uint4 v0 = pv[i], v1 = pv[i + stride], v2 = pv[i + 2u * stride], v3 = pv[i + 3u * stride];
+    histAdd4(myBins, v0.x); histAdd4(myBins, v0.y); histAdd4(myBins, v0.z); histAdd4(myBins, v0.w);
+    histAdd4(myBins, v1.x); histAdd4(myBins, v1.y); histAdd4(myBins, v1.z); histAdd4(myBins, v1.w);
+    histAdd4(myBins, v2.x); histAdd4(myBins, v2.y); histAdd4(myBins, v2.z); histAdd4(myBins, v2.w);
+    histAdd4(myBins, v3.x); histAdd4(myBins, v3.y); histAdd4(myBins, v3.z); histAdd4(myBins, v3.w);
+  }
+  for (; i < numVec; i += stride) {
+    const uint4 v = pv[i];
     histAdd4(myBins, v.x);
     histAdd4(myBins, v.y);
     histAdd4(myBins, v.z);
@@ -97,8 +114,8 @@ __global__ __launch_bounds__(256) void k_histogram(BatchView in, uint32_t* __res
   }
 
   if (blockIdx.x == 0) {
-    uint32_t i = numVec * 16u + tid;
-    if (i < remaining) atomicAdd(&myBins[p[head + i]], 1u);
+    uint32_t t = numVec * 16u + tid;
+    if (t < remaining) histAdd(myBins, p[head + t]);
   }
   __syncthreads();
 
