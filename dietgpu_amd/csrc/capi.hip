@@ -403,6 +403,7 @@ int encodeCommon(
     e.out = archives;
     e.encTable = table;
     e.maxTiles = maxTiles;
+    e.numInBatch = B;
     e.tileDesc = tileDesc;
     e.ticket = ticket;
     e.outSize = outSize_dev;
@@ -506,7 +507,7 @@ int floatCompressImpl(
 
 template <int P, uint32_t FT>
 int launchDecodePF(const DecodeArgs& a, dim3 grid, hipStream_t stream) {
-  DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode<P, FT>), grid, dim3(256), decLdsBytes(P), stream, a);
+  DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode<P, FT>), grid, dim3(kDecThreads), decLdsBytes(P), stream, a);
   DGPU_HIP(hipGetLastError());
   return DGPU_OK;
 }
@@ -563,7 +564,7 @@ int decodeImpl(
     }
   }
 
-  const uint32_t maxTiles = std::max(1u, tilesFor(maxCapacity));
+  const uint32_t maxTiles = std::max(1u, divUp(divUp(maxCapacity, kBlockSize), kDecBlocksPerTile));
   {
     DecodeArgs d;
     d.in = in;

@@ -183,8 +183,13 @@ constexpr uint32_t kRingChunkWords = 256;
 constexpr uint32_t kRingBytes = 2048;
 constexpr uint32_t kGroupRows = 8;
 
+// A decode workgroup is 8 wavefronts = 16 blocks sharing one LUT: 32 KiB of
+// rings + 8 KiB LUT (P = 10) lets 4 workgroups = 32 wavefronts (the maximum)
+// reside on a CU.
+constexpr uint32_t kDecBlocksPerTile = 16;
+constexpr uint32_t kDecThreads = kDecBlocksPerTile * 32u;
 __host__ __device__ constexpr uint32_t decLdsBytes(int P) {
-  return (8u << P) + kBlocksPerTile * kRingBytes;
+  return (8u << P) + kDecBlocksPerTile * kRingBytes;
 }
 
 template <int P, uint32_t FT, bool kFull>
@@ -303,12 +308,12 @@ __device__ __forceinline__ void decodeBlock(
   }
 }
 
-// grid = (maxTiles, B), 256 threads, LDS = 64-bit LUT + 8 word rings.
+// grid = (maxTiles, B), 512 threads, LDS = 16 word rings + 64-bit LUT.
 template <int P, uint32_t FT>
-__global__ __launch_bounds__(256) void k_ans_decode(DecodeArgs a) {
+__global__ __launch_bounds__(kDecThreads) void k_ans_decode(DecodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  // rings: 8 x 2 KiB at LDS offset 0 (2 KiB aligned), then the LUT
-  uint2* sLut = (uint2*)(smem + kBlocksPerTile * kRingBytes);
+  // rings: 16 x 2 KiB at LDS offset 0 (2 KiB aligned), then the LUT
+  uint2* sLut = (uint2*)(smem + kDecBlocksPerTile * kRingBytes);
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
@@ -336,15 +341,15 @@ __global__ __launch_bounds__(256) void k_ans_decode(DecodeArgs a) {
     if (a.outSuccess) a.outSuccess[b] = success ? 1 : 0;
     if (a.outSize) a.outSize[b] = total;
   }
-  if (!success || tile * kBlocksPerTile >= nb) return;
+  if (!success || tile * kDecBlocksPerTile >= nb) return;
 
   {
     const uint4* src = (const uint4*)(a.lut + ((size_t)b << P));
     uint4* dst = (uint4*)sLut;
-    for (uint32_t i = tid; i < (1u << P) / 2u; i += 256u) dst[i] = src[i];
+    for (uint32_t i = tid; i < (1u << P) / 2u; i += kDecThreads) dst[i] = src[i];
   }
 
-  const uint32_t block = tile * kBlocksPerTile + hw;
+  const uint32_t block = tile * kDecBlocksPerTile + hw;
   const bool haveBlock = block < nb;
 
   uint32_t state = 0, n = 0, numWords = 0, start = 0;
