@@ -163,9 +163,9 @@ def algorithmic_bytes(kernel, codec, comp_total):
         nc = E * (wb - 1)                      # non-compressed plane bytes
         ans = comp_total - 16 * codec.B - nc   # compressed exponent archives
         return {
-            "k_float_split": E * wb + nc + E,  # read words, write non-comp plane + exponent plane
-            "k_ans_encode": E + ans,           # read exponent plane, write archive
-            "k_ans_decode": ans + nc + E * wb, # read archive + non-comp plane, write words
+            "k_float_histogram": E * wb,            # read the float words once
+            "k_ans_encode": E * wb + nc + ans,      # read words, write non-comp plane + rANS archive (split fused in)
+            "k_ans_decode": ans + nc + E * wb,      # read archive + non-comp plane, write words (join fused in)
         }.get(kernel)
     return {
         "k_histogram": E,
@@ -237,13 +237,13 @@ def main():
     distributed = world > 1
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    import dietgpu_amd as dg
+    from dietgpu_amd import distributed as D
+
     if distributed:
         import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
-
-    import dietgpu_amd as dg
+        D.init(backend="nccl", device=device)  # "nccl" is RCCL on ROCm
 
     data, ft, _, prob_bits, desc = make_workload(args.workload, args.batch, 1234 + rank, device)
     codec = Codec(dg, data, ft, prob_bits)
@@ -265,9 +265,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = D.max_over_ranks(elapsed, device)
     codec.verify()
 
     # separate encode / decode timings (HIP events on the launch stream)
@@ -287,9 +285,8 @@ def main():
     comp_total = int(sizes.sum().item())
     if distributed:
         # the only collective: all-gather the per-element compressed sizes (RCCL over xGMI)
-        gathered = [torch.empty_like(codec.sizes) for _ in range(world)]
-        dist.all_gather(gathered, codec.sizes)
-        ratio = float(sum(int(g.to(torch.int64).sum().item()) for g in gathered)) / (codec.in_bytes * world)
+        all_sizes = D.gather_sizes(codec.sizes, args.batch * world)
+        ratio = float(all_sizes.to(torch.int64).sum().item()) / (codec.in_bytes * world)
     else:
         ratio = comp_total / codec.in_bytes
 

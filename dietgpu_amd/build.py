@@ -32,5 +32,29 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+TORCH_LIB_PATH = os.path.join(LIB_DIR, "libdietgpu_torch.so")
+
+
+def build_torch_ops(force=False, verbose=False):
+    """torch.ops.dietgpu.* (csrc/torch_ops.cpp): plain host C++ against PyTorch-ROCm and the C ABI."""
+    src = os.path.join(CSRC, "torch_ops.cpp")
+    if (not force and os.path.exists(TORCH_LIB_PATH)
+            and os.path.getmtime(TORCH_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(LIB_PATH))):
+        return TORCH_LIB_PATH
+    import torch
+
+    tl = os.path.dirname(torch.__file__)
+    abi = int(torch._C._GLIBCXX_USE_CXX11_ABI)
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM",
+           f"-D_GLIBCXX_USE_CXX11_ABI={abi}", f"-I{tl}/include", f"-I{tl}/include/torch/csrc/api/include",
+           "-I/opt/rocm/include", src, "-o", TORCH_LIB_PATH, f"-L{LIB_DIR}", "-ldietgpu_amd", f"-L{tl}/lib",
+           "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return TORCH_LIB_PATH
+
+
 if __name__ == "__main__":
     build(force=True, verbose=True)
+    build_torch_ops(force=True, verbose=True)

@@ -1,0 +1,86 @@
+"""N > 1 path on CPU: world_size-2 gloo processes exercise the batch sharding,
+the compressed-size all-gather and the max-over-ranks timing reduction that
+bench.py uses on RCCL.  The per-rank codec here is the CPU oracle (test
+infrastructure): what is under test is the distributed plumbing."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, num_elements, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+
+    import oracle as O
+    import refgen
+    from dietgpu_amd import distributed as D
+
+    D.init(backend="gloo")
+    start, end = D.shard_range(num_elements, rank, world)
+    sizes = []
+    for e in range(start, end):
+        w = refgen.generate_floats(O.BFLOAT16, 1000 + 37 * e)
+        sizes.append(O.float_compress(O.BFLOAT16, w, 10).size)
+    local = torch.tensor(sizes, dtype=torch.int32)
+    full = D.gather_sizes(local, num_elements)
+    t = D.max_over_ranks(1.0 + rank, torch.device("cpu"))
+    dist.barrier()
+    q.put((rank, start, end, full.tolist(), t))
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions_exactly():
+    sys.path.insert(0, ROOT)
+    from dietgpu_amd.distributed import shard_range
+
+    for n in (0, 1, 7, 8, 256, 2048, 2049):
+        for world in (1, 2, 3, 8):
+            covered = []
+            for r in range(world):
+                s, e = shard_range(n, r, world)
+                assert 0 <= s <= e <= n
+                covered.extend(range(s, e))
+            assert covered == list(range(n))
+    assert shard_range(2048, 3, 8) == (768, 1024)  # BASELINE config 5: 256 elements per GPU
+
+
+def test_two_rank_gloo_size_allgather():
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+    import refgen
+
+    world, n = 2, 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [O.float_compress(O.BFLOAT16, refgen.generate_floats(O.BFLOAT16, 1000 + 37 * e), 10).size for e in range(n)]
+    seen = set()
+    for rank, start, end, full, t in results:
+        assert full == want          # every rank sees the whole batch's sizes
+        assert t == 2.0              # max over ranks of (1 + rank)
+        seen.update(range(start, end))
+    assert seen == set(range(n))

@@ -1,0 +1,17 @@
+#!/bin/bash
+# rocprofv3 kernel-trace stats of the default bench command + PMC passes; writes text summaries
+# under gpurun_out/ (copy the ones to keep into profiles/).  Usage: gpurun -- tools/gpu_profile.sh <tag> [workload]
+TAG=${1:-run}; WL=${2:-bf16}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp
+mkdir -p $R/gpurun_out /tmp/prof_$TAG
+CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload $WL"
+rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG/stats -o bench -- $CMD > /tmp/prof_$TAG/bench.json 2> /tmp/prof_$TAG/err.log
+{
+  echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload $WL"
+  python $R/tools/rocpd_summary.py stats /tmp/prof_$TAG/stats/bench_results.db | grep -v "at::native\|rocclr\|elementwise"
+  echo
+  echo "# bench line printed by the same (profiled) command"
+  cat /tmp/prof_$TAG/bench.json
+} > $R/gpurun_out/rocprof_${TAG}_$WL.txt
+cat $R/gpurun_out/rocprof_${TAG}_$WL.txt | head -12
