@@ -229,6 +229,8 @@ def main():
     ap.add_argument("--workload", default="bf16", choices=["bf16", "u8", "fp16"])
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timeline", action="store_true",
+                    help="only the timed steps (no per-phase timing / kernel profile): for rocprofv3 timelines")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -277,6 +279,11 @@ def main():
         e.record()
         torch.cuda.synchronize()
         return s.elapsed_time(e) / reps
+
+    if args.timeline:
+        if rank == 0:
+            print(json.dumps({"ms_per_step": round(elapsed / args.steps * 1e3, 4)}))
+        return
 
     enc_ms = timed(codec.encode, args.steps)
     dec_ms = timed(codec.decode, args.steps)

@@ -5,7 +5,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libdietgpu_amd.so")
+# DGPU_LIB: developer override used to A/B experimental builds of the same sources
+LIB_PATH = os.environ.get("DGPU_LIB") or os.path.join(LIB_DIR, "libdietgpu_amd.so")
 
 _SOURCES = ["capi.hip"]
 _DEPS = ["format.h", "kernels_stats.h", "kernels_encode.h", "kernels_decode.h", "kernels_float.h",

@@ -174,64 +174,72 @@ class TempArena {
   } while (0)
 
 // ---------------------------------------------------------------------------
-// Host->device parameter upload (pointer / size arrays) through a small ring of
-// pinned buffers, so the copy is a true async DMA and never forces the host to
-// wait for earlier work on the stream.  A slot is reused only after the copy
-// that last read it has completed (event-guarded).
+// Host->device parameter upload (pointer / size arrays).  The parameters of a
+// call live in a small library-owned ring of {pinned host buffer, device buffer}
+// slots per device, NOT in the caller's temp memory: that lets the H2D copy run
+// on a private copy stream as soon as the call is issued -- overlapping the
+// kernels of the previous call still executing on the caller's stream --
+// instead of sitting on the critical path as a ~6 us blit between two kernels.
+// The caller's stream waits on the copy's event before its first kernel; a slot
+// is reused only after the kernels that read it have finished (event recorded
+// on the caller's stream when the call has been enqueued).
 class ParamStager {
  public:
   struct Slot {
     void* host = nullptr;
+    void* dev = nullptr;
     size_t cap = 0;
-    hipEvent_t ev = nullptr;
-    bool pending = false;
+    hipEvent_t copied = nullptr;   // H2D done (copy stream)
+    hipEvent_t released = nullptr; // kernels of the call done (caller's stream)
+    bool inFlight = false;
   };
 
-  // Returns a pinned host buffer of at least `bytes`.
-  hipError_t acquire(size_t bytes, Slot** out) {
+  hipError_t acquire(size_t bytes, Slot** out, hipStream_t* copyStream) {
     std::lock_guard<std::mutex> g(mu_);
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     Ring& r = rings_[dev];
+    if (!r.copyStream) {
+      e = hipStreamCreateWithFlags(&r.copyStream, hipStreamNonBlocking);
+      if (e != hipSuccess) return e;
+    }
     Slot& s = r.slots[r.next];
     r.next = (r.next + 1) % kSlots;
-    if (s.pending) {
-      e = hipEventSynchronize(s.ev);
+    if (s.inFlight) {
+      e = hipEventSynchronize(s.released);
       if (e != hipSuccess) return e;
-      s.pending = false;
+      s.inFlight = false;
     }
     if (s.cap < bytes) {
       if (s.host) (void)hipHostFree(s.host);
-      s.host = nullptr;
+      if (s.dev) (void)hipFree(s.dev);
+      s.host = s.dev = nullptr;
       s.cap = 0;
       size_t cap = std::max<size_t>(alignUp(bytes, 4096), 16384);
       e = hipHostMalloc(&s.host, cap, hipHostMallocDefault);
       if (e != hipSuccess) return e;
+      e = hipMalloc(&s.dev, cap);
+      if (e != hipSuccess) return e;
       s.cap = cap;
     }
-    if (!s.ev) {
-      e = hipEventCreateWithFlags(&s.ev, hipEventDisableTiming);
+    if (!s.copied) {
+      e = hipEventCreateWithFlags(&s.copied, hipEventDisableTiming);
+      if (e != hipSuccess) return e;
+      e = hipEventCreateWithFlags(&s.released, hipEventDisableTiming);
       if (e != hipSuccess) return e;
     }
     *out = &s;
-    return hipSuccess;
-  }
-
-  hipError_t upload(Slot* s, void* dst_dev, size_t bytes, hipStream_t stream) {
-    hipError_t e = hipMemcpyAsync(dst_dev, s->host, bytes, hipMemcpyHostToDevice, stream);
-    if (e != hipSuccess) return e;
-    e = hipEventRecord(s->ev, stream);
-    if (e != hipSuccess) return e;
-    s->pending = true;
+    *copyStream = r.copyStream;
     return hipSuccess;
   }
 
  private:
-  static constexpr int kSlots = 16;
+  static constexpr int kSlots = 32;
   struct Ring {
     Slot slots[kSlots];
     int next = 0;
+    hipStream_t copyStream = nullptr;
   };
   std::mutex mu_;
   std::map<int, Ring> rings_;
@@ -241,6 +249,28 @@ ParamStager& stager() {
   static ParamStager* s = new ParamStager();  // intentionally leaked: no teardown-order issues
   return *s;
 }
+
+// Marks the parameter slot of a call as released once everything the call
+// enqueued on the caller's stream has executed.
+class ParamLease {
+ public:
+  ParamLease() = default;
+  ParamLease(const ParamLease&) = delete;
+  ParamLease& operator=(const ParamLease&) = delete;
+  ~ParamLease() {
+    if (slot_) {
+      if (hipEventRecord(slot_->released, stream_) == hipSuccess) slot_->inFlight = true;
+    }
+  }
+  void bind(ParamStager::Slot* s, hipStream_t stream) {
+    slot_ = s;
+    stream_ = stream;
+  }
+
+ private:
+  ParamStager::Slot* slot_ = nullptr;
+  hipStream_t stream_ = nullptr;
+};
 
 BatchView viewStride(const void* base, uint64_t stride, uint32_t uniformSize) {
   BatchView v;
@@ -293,23 +323,26 @@ struct HostParams {
 };
 
 int uploadParams(
-    TempArena& arena, hipStream_t stream, uint32_t B, const HostParams& hp,
+    ParamLease& lease, hipStream_t stream, const HostParams& hp,
     const uint64_t** inPtrs_dev, const uint64_t** outPtrs_dev, const uint32_t** sizes_dev) {
   const size_t nIn = hp.inPtrs.size(), nOut = hp.outPtrs.size(), nSz = hp.sizes.size();
   const size_t bytes = (nIn + nOut) * 8 + alignUp(nSz * 4, 8);
   if (bytes == 0) return DGPU_OK;
-  DGPU_ALLOC(dev, uint8_t, arena, bytes);
   ParamStager::Slot* slot = nullptr;
-  DGPU_HIP(stager().acquire(bytes, &slot));
+  hipStream_t copyStream = nullptr;
+  DGPU_HIP(stager().acquire(bytes, &slot, &copyStream));
   uint8_t* h = (uint8_t*)slot->host;
   if (nIn) memcpy(h, hp.inPtrs.data(), nIn * 8);
   if (nOut) memcpy(h + nIn * 8, hp.outPtrs.data(), nOut * 8);
   if (nSz) memcpy(h + (nIn + nOut) * 8, hp.sizes.data(), nSz * 4);
-  DGPU_HIP(stager().upload(slot, dev, bytes, stream));
+  DGPU_HIP(hipMemcpyAsync(slot->dev, slot->host, bytes, hipMemcpyHostToDevice, copyStream));
+  DGPU_HIP(hipEventRecord(slot->copied, copyStream));
+  DGPU_HIP(hipStreamWaitEvent(stream, slot->copied, 0));
+  lease.bind(slot, stream);
+  uint8_t* dev = (uint8_t*)slot->dev;
   *inPtrs_dev = nIn ? (const uint64_t*)dev : nullptr;
   *outPtrs_dev = nOut ? (const uint64_t*)(dev + nIn * 8) : nullptr;
   *sizes_dev = nSz ? (const uint32_t*)(dev + (nIn + nOut) * 8) : nullptr;
-  (void)B;
   return DGPU_OK;
 }
 
@@ -317,72 +350,146 @@ int uploadParams(
 // Launch sequences
 // ---------------------------------------------------------------------------
 
+uint32_t numComputeUnits() {
+  static std::mutex mu;
+  static std::map<int, uint32_t> cus;
+  std::lock_guard<std::mutex> g(mu);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  auto it = cus.find(dev);
+  if (it != cus.end()) return it->second;
+  hipDeviceProp_t prop;
+  uint32_t n = 256;
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = (uint32_t)prop.multiProcessorCount;
+  cus[dev] = n;
+  return n;
+}
+
+// The encoder runs as persistent workgroups: as many as fit on the chip at once
+// (or fewer, if there are fewer tiles).  Float inputs use the small-stage /
+// spilling variant (6 workgroups per CU), raw bytes the worst-case stage.
+constexpr bool encodeSpills(uint32_t ft) { return ft != 0; }
+
 template <int P, uint32_t FT>
-int launchEncodePF(const EncodeArgs& a, uint32_t tickets, hipStream_t stream) {
-  DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT>), dim3(tickets), dim3(256), encLdsBytes(P), stream, a);
+uint32_t encodeGridPF(uint32_t tickets) {
+  static const uint32_t perCu = [] {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &n, (k_ans_encode<P, FT, encodeSpills(FT)>), 256, encLdsBytes(P, encodeSpills(FT))) != hipSuccess || n < 1) {
+      n = 1;
+    }
+    return (uint32_t)n;
+  }();
+  static const uint32_t knob = [] {
+    const char* e = getenv("DGPU_ENC_WG_PER_CU");  // experiment knob
+    return e ? (uint32_t)atoi(e) : 0u;
+  }();
+  const uint32_t use = knob ? std::min(knob, perCu) : perCu;
+  return std::max(1u, std::min(tickets, use * numComputeUnits()));
+}
+
+template <int P, uint32_t FT>
+int launchEncodePF(const EncodeArgs& a, uint32_t grid, hipStream_t stream) {
+  constexpr bool kSpill = encodeSpills(FT);
+  DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT, kSpill>), dim3(grid), dim3(256), encLdsBytes(P, kSpill), stream, a);
   DGPU_HIP(hipGetLastError());
   return DGPU_OK;
 }
 
-template <uint32_t FT>
-int launchEncodeF(int P, const EncodeArgs& a, uint32_t tickets, hipStream_t stream) {
-  switch (P) {
-    case 9: return launchEncodePF<9, FT>(a, tickets, stream);
-    case 10: return launchEncodePF<10, FT>(a, tickets, stream);
-    default: return launchEncodePF<11, FT>(a, tickets, stream);
+#define DGPU_ENCODE_DISPATCH(P_, FT_, EXPR)                                   \
+  switch (FT_) {                                                              \
+    case 0:                                                                   \
+      switch (P_) { case 9: { constexpr int kP = 9; constexpr uint32_t kFT = 0; EXPR; } break;          \
+                    case 10: { constexpr int kP = 10; constexpr uint32_t kFT = 0; EXPR; } break;        \
+                    default: { constexpr int kP = 11; constexpr uint32_t kFT = 0; EXPR; } break; }      \
+      break;                                                                  \
+    case kFloat16:                                                            \
+      switch (P_) { case 9: { constexpr int kP = 9; constexpr uint32_t kFT = kFloat16; EXPR; } break;   \
+                    case 10: { constexpr int kP = 10; constexpr uint32_t kFT = kFloat16; EXPR; } break; \
+                    default: { constexpr int kP = 11; constexpr uint32_t kFT = kFloat16; EXPR; } break; } \
+      break;                                                                  \
+    case kBFloat16:                                                           \
+      switch (P_) { case 9: { constexpr int kP = 9; constexpr uint32_t kFT = kBFloat16; EXPR; } break;  \
+                    case 10: { constexpr int kP = 10; constexpr uint32_t kFT = kBFloat16; EXPR; } break; \
+                    default: { constexpr int kP = 11; constexpr uint32_t kFT = kBFloat16; EXPR; } break; } \
+      break;                                                                  \
+    default:                                                                  \
+      switch (P_) { case 9: { constexpr int kP = 9; constexpr uint32_t kFT = kFloat32; EXPR; } break;   \
+                    case 10: { constexpr int kP = 10; constexpr uint32_t kFT = kFloat32; EXPR; } break; \
+                    default: { constexpr int kP = 11; constexpr uint32_t kFT = kFloat32; EXPR; } break; } \
+      break;                                                                  \
   }
+
+uint32_t encodeGrid(int P, uint32_t ft, uint32_t tickets) {
+  uint32_t g = 1;
+  DGPU_ENCODE_DISPATCH(P, ft, g = (encodeGridPF<kP, kFT>(tickets)));
+  return g;
 }
 
-int launchEncode(int P, uint32_t ft, const EncodeArgs& a, uint32_t tickets, hipStream_t stream) {
-  switch (ft) {
-    case 0: return launchEncodeF<0>(P, a, tickets, stream);
-    case kFloat16: return launchEncodeF<kFloat16>(P, a, tickets, stream);
-    case kBFloat16: return launchEncodeF<kBFloat16>(P, a, tickets, stream);
-    default: return launchEncodeF<kFloat32>(P, a, tickets, stream);
-  }
+int launchEncode(int P, uint32_t ft, const EncodeArgs& a, uint32_t grid, hipStream_t stream) {
+  int rc = DGPU_OK;
+  DGPU_ENCODE_DISPATCH(P, ft, rc = (launchEncodePF<kP, kFT>(a, grid, stream)));
+  return rc;
 }
+
+uint32_t tilesFor(uint32_t maxSize) { return divUp(divUp(maxSize, kBlockSize), kBlocksPerTile); }
 
 // Shared tail of every encode entry point: [checksum] -> histogram ->
 // normalise -> encode.  `in` holds raw bytes (floatType == 0: the ANS archive is
 // the whole output) or float words (floatType != 0: the encoder splits them on
-// the fly, the archive is a float archive).  The zero region has been cleared.
+// the fly, the archive is a float archive).  No memset is needed on the common
+// path: histogram workgroups store partial histograms that k_normalize sums, and
+// k_normalize clears the tile descriptors + ticket for the encode kernel.
 int encodeCommon(
     TempArena& arena, hipStream_t stream, int P, bool useChecksum, uint32_t B,
     const BatchView& in, const BatchView& archives, uint32_t floatType, uint32_t maxSize,
-    const uint32_t* hist_dev /*may be null*/, uint32_t* histTemp, uint32_t* checksumTemp,
-    uint64_t* tileDesc, uint32_t* ticket, uint32_t maxTiles, uint32_t* outSize_dev) {
+    const uint32_t* hist_dev /*may be null*/, uint32_t* outSize_dev) {
   const uint32_t wordBytes = floatType ? floatWordBytes(floatType) : 1u;
+  const uint32_t maxTiles = tilesFor(maxSize);
+
+  uint32_t* checksumTemp = nullptr;
   if (useChecksum) {
+    DGPU_ALLOC(ck, uint32_t, arena, B);
+    checksumTemp = ck;
+    DGPU_HIP(hipMemsetAsync(checksumTemp, 0, (size_t)B * 4, stream));
     // Float quirk kept from the reference (GpuFloatCompress.cuh:466-468): the
     // size in float WORDS is consumed as a BYTE count by the checksum.
     dim3 grid(gridX(maxSize, 64 * 1024, 64), B);
     DGPU_LAUNCH("k_checksum", stream, k_checksum, grid, dim3(256), 0, stream, in, (const uint32_t*)nullptr, checksumTemp);
     DGPU_HIP(hipGetLastError());
   }
+
+  uint32_t histParts = 1;
   if (!hist_dev) {
     dim3 grid(gridX(maxSize * wordBytes, 32 * 1024, 64), B);
+    histParts = grid.x;
+    DGPU_ALLOC(histTemp, uint32_t, arena, (size_t)B * histParts * kNumSymbols);
     switch (floatType) {
       case 0:
-        DGPU_LAUNCH("k_histogram", stream, k_histogram, grid, dim3(256), 0, stream, in, histTemp);
+        DGPU_LAUNCH("k_histogram", stream, k_histogram, grid, dim3(256), 0, stream, in, histTemp, 1u);
         break;
       case kFloat16:
-        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kFloat16>), grid, dim3(256), 0, stream, in, histTemp);
+        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kFloat16>), grid, dim3(256), 0, stream, in, histTemp, 1u);
         break;
       case kBFloat16:
-        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kBFloat16>), grid, dim3(256), 0, stream, in, histTemp);
+        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kBFloat16>), grid, dim3(256), 0, stream, in, histTemp, 1u);
         break;
       default:
-        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kFloat32>), grid, dim3(256), 0, stream, in, histTemp);
+        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kFloat32>), grid, dim3(256), 0, stream, in, histTemp, 1u);
         break;
     }
     DGPU_HIP(hipGetLastError());
     hist_dev = histTemp;
   }
+
   DGPU_ALLOC(table, uint4, arena, (size_t)B * kNumSymbols);
+  DGPU_ALLOC(tileDesc, uint64_t, arena, (size_t)B * std::max(maxTiles, 1u) + 1);
+  uint32_t* ticket = (uint32_t*)(tileDesc + (size_t)B * std::max(maxTiles, 1u));
   {
     NormalizeArgs n;
     n.sizes = in;
     n.hist = hist_dev;
+    n.histParts = histParts;
     n.probBits = P;
     n.encTable = table;
     n.refTable = nullptr;
@@ -394,40 +501,37 @@ int encodeCommon(
     n.checksum = (useChecksum && !floatType) ? checksumTemp : nullptr;
     n.outSize = outSize_dev;
     n.floatUseChecksum = (useChecksum && floatType) ? 1 : 0;
+    n.tileDesc = tileDesc;
+    n.maxTiles = maxTiles;
+    n.ticket = ticket;
     DGPU_LAUNCH("k_normalize", stream, k_normalize, dim3(B), dim3(256), 0, stream, n);
     DGPU_HIP(hipGetLastError());
   }
   if (maxTiles > 0) {
+    const uint32_t grid = encodeGrid(P, floatType, B * maxTiles);
+    uint16_t* spill = nullptr;
+    if (encodeSpills(floatType)) {
+      DGPU_ALLOC(sp, uint16_t, arena, (size_t)grid * kBlocksPerTile * encSpillSlotWords(P));
+      spill = sp;
+    }
     EncodeArgs e;
     e.in = in;
     e.out = archives;
     e.encTable = table;
     e.maxTiles = maxTiles;
     e.numInBatch = B;
+    e.numTickets = B * maxTiles;
     e.tileDesc = tileDesc;
     e.ticket = ticket;
+    e.spill = spill;
     e.outSize = outSize_dev;
     e.useChecksum = (useChecksum && floatType) ? 1 : 0;
     e.checksum = (useChecksum && floatType) ? checksumTemp : nullptr;
-    int rc = launchEncode(P, floatType, e, B * maxTiles, stream);
+    int rc = launchEncode(P, floatType, e, grid, stream);
     if (rc) return rc;
   }
   return DGPU_OK;
 }
-
-uint32_t tilesFor(uint32_t maxSize) { return divUp(divUp(maxSize, kBlockSize), kBlocksPerTile); }
-
-// One region zeroed by a single memset per encode call (u32 words):
-//   [hist B*256 (optional)][checksum B (+pad to even)][ticket, pad][tileDesc B*maxTiles u64]
-struct ZeroLayout {
-  size_t checksumAt, ticketAt, descAt, words;
-  ZeroLayout(size_t histWords, uint32_t B, uint32_t maxTiles) {
-    checksumAt = histWords;
-    ticketAt = checksumAt + roundUp(B, 2u);
-    descAt = ticketAt + 2;
-    words = descAt + 2 * (size_t)B * maxTiles;
-  }
-};
 
 int ansEncodeImpl(
     void* temp_dev, size_t tempBytes, size_t* tempUsed, int P, int useChecksum, uint32_t B,
@@ -440,11 +544,12 @@ int ansEncodeImpl(
   if (B == 0) return DGPU_OK;
 
   TempArena arena(temp_dev, tempBytes, stream);
+  ParamLease lease;
   BatchView in, out;
   if (hp) {
     const uint64_t *inP = nullptr, *outP = nullptr;
     const uint32_t* sz = nullptr;
-    int rc = uploadParams(arena, stream, B, *hp, &inP, &outP, &sz);
+    int rc = uploadParams(lease, stream, *hp, &inP, &outP, &sz);
     if (rc) return rc;
     in = viewPointers(inP, sz, 0);
     out = viewPointers(outP, nullptr, 0);
@@ -452,20 +557,7 @@ int ansEncodeImpl(
     in = *strideIn;
     out = *strideOut;
   }
-
-  const uint32_t maxTiles = tilesFor(maxSize);
-  const ZeroLayout zl(histogram_dev ? 0 : (size_t)B * kNumSymbols, B, maxTiles);
-  DGPU_ALLOC(zero, uint32_t, arena, zl.words);
-  const size_t zeroWords = zl.words;
-  uint32_t* histTemp = zero;
-  uint32_t* checksumTemp = zero + zl.checksumAt;
-  uint32_t* ticket = zero + zl.ticketAt;
-  uint64_t* tileDesc = (uint64_t*)(zero + zl.descAt);
-
-  DGPU_HIP(hipMemsetAsync(zero, 0, zeroWords * 4, stream));
-  int rc = encodeCommon(
-      arena, stream, P, useChecksum != 0, B, in, out, 0, maxSize, histogram_dev, histTemp,
-      checksumTemp, tileDesc, ticket, maxTiles, outSize_dev);
+  int rc = encodeCommon(arena, stream, P, useChecksum != 0, B, in, out, 0, maxSize, histogram_dev, outSize_dev);
   if (tempUsed) *tempUsed = arena.requested();
   return rc;
 }
@@ -481,26 +573,16 @@ int floatCompressImpl(
   if (B == 0) return DGPU_OK;
 
   TempArena arena(temp_dev, tempBytes, stream);
+  ParamLease lease;
   const uint64_t *inP = nullptr, *outP = nullptr;
   const uint32_t* sz = nullptr;
-  int rc = uploadParams(arena, stream, B, hp, &inP, &outP, &sz);
+  int rc = uploadParams(lease, stream, hp, &inP, &outP, &sz);
   if (rc) return rc;
   BatchView in = viewPointers(inP, sz, 0);
   BatchView out = viewPointers(outP, nullptr, 0);
 
-  const uint32_t maxTiles = tilesFor(maxSize);
-  const ZeroLayout zl((size_t)B * kNumSymbols, B, maxTiles);
-  DGPU_ALLOC(zero, uint32_t, arena, zl.words);
-  uint32_t* histTemp = zero;
-  uint32_t* checksumTemp = zero + zl.checksumAt;
-  uint32_t* ticket = zero + zl.ticketAt;
-  uint64_t* tileDesc = (uint64_t*)(zero + zl.descAt);
-  DGPU_HIP(hipMemsetAsync(zero, 0, zl.words * 4, stream));
-
   // No exponent plane in temp memory: the encoder splits the float words itself.
-  rc = encodeCommon(
-      arena, stream, P, useChecksum != 0, B, in, out, ft, maxSize, nullptr, histTemp, checksumTemp,
-      tileDesc, ticket, maxTiles, outSize_dev);
+  rc = encodeCommon(arena, stream, P, useChecksum != 0, B, in, out, ft, maxSize, nullptr, outSize_dev);
   if (tempUsed) *tempUsed = arena.requested();
   return rc;
 }
@@ -534,11 +616,12 @@ int decodeImpl(
   if (B == 0) return DGPU_OK;
 
   TempArena arena(temp_dev, tempBytes, stream);
+  ParamLease lease;
   BatchView in, out;
   if (hp) {
     const uint64_t *inP = nullptr, *outP = nullptr;
     const uint32_t* cap = nullptr;
-    int rc = uploadParams(arena, stream, B, *hp, &inP, &outP, &cap);
+    int rc = uploadParams(lease, stream, *hp, &inP, &outP, &cap);
     if (rc) return rc;
     in = viewPointers(inP, nullptr, 0);
     out = viewPointers(outP, cap, 0);
@@ -710,27 +793,38 @@ uint32_t dgpu_float_max_compressed_size(uint32_t ft, uint32_t n) {
   return 16u + maxCompressedSizeHost(n) + floatUncompDataSize(ft, n);
 }
 
-size_t dgpu_ans_encode_temp_bytes(uint32_t B, uint32_t maxBytes) {
-  size_t tiles = tilesFor(maxBytes);
+static size_t encodeTempBytes(uint32_t B, uint32_t maxBytes, uint32_t wordBytes, bool spills) {
+  size_t tiles = std::max(tilesFor(maxBytes), 1u);
+  size_t parts = gridX(maxBytes * wordBytes, 32 * 1024, 64);
   size_t t = 0;
-  t += alignUp((size_t)B * 20 + 8, kTempAlign);                                   // params
-  t += alignUp(ZeroLayout((size_t)B * kNumSymbols, B, (uint32_t)tiles).words * 4, kTempAlign);  // zeroed region
-  t += alignUp((size_t)B * kNumSymbols * 16, kTempAlign);                         // table
+  t += alignUp((size_t)B * 4, kTempAlign);                                        // checksums
+  t += alignUp((size_t)B * parts * kNumSymbols * 4, kTempAlign);                  // partial histograms
+  t += alignUp((size_t)B * kNumSymbols * 16, kTempAlign);                         // encoder table
+  t += alignUp(((size_t)B * tiles + 1) * 8, kTempAlign);                          // tile descriptors + ticket
+  if (spills) {
+    // spill slots of the persistent encoder workgroups (bounded by what fits on the chip)
+    size_t perCu = (160u * 1024u) / encLdsBytes(9, true);
+    size_t grid = std::min((size_t)B * tiles, perCu * numComputeUnits());
+    t += alignUp(grid * kBlocksPerTile * encSpillSlotWords(11) * 2, kTempAlign);
+  }
   return t + kTempAlign;
+}
+
+size_t dgpu_ans_encode_temp_bytes(uint32_t B, uint32_t maxBytes) {
+  return encodeTempBytes(B, maxBytes, 1, encodeSpills(0));
 }
 
 size_t dgpu_ans_decode_temp_bytes(uint32_t B, uint32_t maxBytes, int probBits) {
   (void)maxBytes;
   size_t t = 0;
-  t += alignUp((size_t)B * 20 + 8, kTempAlign);
   t += alignUp(((size_t)B << probBits) * 8, kTempAlign);
   t += 3 * alignUp((size_t)B * 8, kTempAlign);  // checksum verification scratch
   return t + kTempAlign;
 }
 
 size_t dgpu_float_compress_temp_bytes(uint32_t ft, uint32_t B, uint32_t maxFloats) {
-  (void)ft;
-  return dgpu_ans_encode_temp_bytes(B, maxFloats);  // no exponent plane: the split is fused into the encoder
+  // no exponent plane: the split is fused into the encoder
+  return encodeTempBytes(B, maxFloats, validFloatType(ft) ? floatWordBytes(ft) : 4u, true);
 }
 
 size_t dgpu_float_decompress_temp_bytes(uint32_t ft, uint32_t B, uint32_t maxFloats, int probBits) {
@@ -893,13 +987,15 @@ int dgpu_ans_get_compressed_info(
     void* temp_dev, size_t tempBytes, const void* const* in, uint32_t numInBatch,
     uint32_t* outSizes_dev, uint32_t* outChecksum_dev, void* stream) {
   if (numInBatch == 0 || (!outSizes_dev && !outChecksum_dev)) return DGPU_OK;
-  TempArena arena(temp_dev, tempBytes, (hipStream_t)stream);
+  (void)temp_dev;
+  (void)tempBytes;
+  ParamLease lease;
   HostParams hp;
   hp.inPtrs.resize(numInBatch);
   for (uint32_t i = 0; i < numInBatch; ++i) hp.inPtrs[i] = (uint64_t)(uintptr_t)in[i];
   const uint64_t *inP = nullptr, *outP = nullptr;
   const uint32_t* sz = nullptr;
-  int rc = uploadParams(arena, (hipStream_t)stream, numInBatch, hp, &inP, &outP, &sz);
+  int rc = uploadParams(lease, (hipStream_t)stream, hp, &inP, &outP, &sz);
   if (rc) return rc;
   return dgpu_ans_get_compressed_info_device((const void* const*)inP, numInBatch, outSizes_dev,
                                              outChecksum_dev, stream);
@@ -920,13 +1016,15 @@ int dgpu_float_get_compressed_info(
     void* temp_dev, size_t tempBytes, const void* const* in, uint32_t numInBatch,
     uint32_t* outSizes_dev, uint32_t* outTypes_dev, uint32_t* outChecksum_dev, void* stream) {
   if (numInBatch == 0 || (!outSizes_dev && !outTypes_dev && !outChecksum_dev)) return DGPU_OK;
-  TempArena arena(temp_dev, tempBytes, (hipStream_t)stream);
+  (void)temp_dev;
+  (void)tempBytes;
+  ParamLease lease;
   HostParams hp;
   hp.inPtrs.resize(numInBatch);
   for (uint32_t i = 0; i < numInBatch; ++i) hp.inPtrs[i] = (uint64_t)(uintptr_t)in[i];
   const uint64_t *inP = nullptr, *outP = nullptr;
   const uint32_t* sz = nullptr;
-  int rc = uploadParams(arena, (hipStream_t)stream, numInBatch, hp, &inP, &outP, &sz);
+  int rc = uploadParams(lease, (hipStream_t)stream, hp, &inP, &outP, &sz);
   if (rc) return rc;
   return dgpu_float_get_compressed_info_device((const void* const*)inP, numInBatch, outSizes_dev,
                                                outTypes_dev, outChecksum_dev, stream);
@@ -1006,7 +1104,7 @@ int dgpu_ans_histogram_batch_stride(
   DGPU_HIP(hipMemsetAsync(histogram_dev, 0, (size_t)numInBatch * kNumSymbols * 4, (hipStream_t)stream));
   BatchView in = viewStride(in_dev, inPerBatchStride, inPerBatchSize);
   dim3 grid(gridX(inPerBatchSize, 32 * 1024, 64), numInBatch);
-  hipLaunchKernelGGL(k_histogram, grid, dim3(256), 0, (hipStream_t)stream, in, histogram_dev);
+  hipLaunchKernelGGL(k_histogram, grid, dim3(256), 0, (hipStream_t)stream, in, histogram_dev, 0u);
   DGPU_HIP(hipGetLastError());
   return DGPU_OK;
 }
@@ -1019,6 +1117,7 @@ int dgpu_ans_calc_weights(
   NormalizeArgs n;
   n.sizes = viewPointers(nullptr, sizes_dev, uniformSize);
   n.hist = histogram_dev;
+  n.histParts = 1;
   n.probBits = probBits;
   n.encTable = nullptr;
   n.refTable = (uint4*)table_dev;
@@ -1029,6 +1128,9 @@ int dgpu_ans_calc_weights(
   n.checksum = nullptr;
   n.outSize = nullptr;
   n.floatUseChecksum = 0;
+  n.tileDesc = nullptr;
+  n.maxTiles = 0;
+  n.ticket = nullptr;
   hipLaunchKernelGGL(k_normalize, dim3(numInBatch), dim3(256), 0, (hipStream_t)stream, n);
   DGPU_HIP(hipGetLastError());
   return DGPU_OK;

@@ -17,7 +17,51 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Streaming (non-temporal) access helpers.  kNt selects the cache policy at the
+// call site; the DGPU_NT_* macros are the A/B knobs the defaults were chosen with
+// ("cache policy"):
+//   * decoded float words are written once and not read again by the codec: if
+//     they are left dirty in the 256 MiB memory-side cache, the NEXT kernel pays
+//     for their write-back (the histogram pass ran at 3.5 TB/s instead of 5.5)
+//   * the encoder's and the histogram's input reads are one-shot streams that
+//     would only evict the archive being written
+//   * archive stores stay cacheable: the consumer (decode, a send) follows soon
+#ifndef DGPU_NT_DEC_STORES
+#define DGPU_NT_DEC_STORES 1
+#endif
+#ifndef DGPU_NT_ENC_STORES
+#define DGPU_NT_ENC_STORES 0
+#endif
+#ifndef DGPU_NT_HIST_LOADS
+#define DGPU_NT_HIST_LOADS 1
+#endif
+#ifndef DGPU_NT_ENC_LOADS
+#define DGPU_NT_ENC_LOADS 1
+#endif
+
 namespace dgpu {
+
+typedef uint32_t dgpu_u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool kNt, typename T>
+__device__ __forceinline__ void streamStore(T* p, const T& v) {
+  if (kNt) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+template <bool kNt>
+__device__ __forceinline__ void streamStore(uint4* p, const uint4& v) {
+  if (kNt) __builtin_nontemporal_store(dgpu_u32x4{v.x, v.y, v.z, v.w}, (dgpu_u32x4*)p);
+  else *p = v;
+}
+template <bool kNt>
+__device__ __forceinline__ uint4 streamLoad(const uint4* p) {
+  if (kNt) {
+    const dgpu_u32x4 v = __builtin_nontemporal_load((const dgpu_u32x4*)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+  }
+  return *p;
+}
+
 
 constexpr uint32_t kNumSymbols = 256;
 constexpr uint32_t kBlockSize = 4096;      // kDefaultBlockSize, GpuANSUtils.cuh:37

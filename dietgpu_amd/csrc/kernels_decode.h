@@ -113,7 +113,7 @@ struct RowSink<0> {  // raw bytes (BatchWriter, BatchProvider.cuh:16-37)
   }
   __device__ __forceinline__ uint32_t prefetch(uint32_t) const { return 0; }
   __device__ __forceinline__ void store(uint32_t row, uint32_t e0, uint32_t) const {
-    out[row * 32u] = (uint8_t)(e0 >> 24);
+    out[row * 32u] = (uint8_t)(e0 >> 24);  // 32-byte row pieces: left to the L2 to merge
   }
 };
 
@@ -128,7 +128,7 @@ struct RowSink<kFloat16> {  // word = comp << 8 | nonComp
   __device__ __forceinline__ uint32_t prefetch(uint32_t row) const { return nc[row * 32u]; }
   __device__ __forceinline__ void store(uint32_t row, uint32_t e0, uint32_t r) const {
     const uint32_t v = (r << 16) | e0;  // [sym][nc][0000 pdf]
-    out[row * 32u] = (uint16_t)(v >> 16);
+    streamStore<DGPU_NT_DEC_STORES != 0>(&out[row * 32u], (uint16_t)(v >> 16));
   }
 };
 
@@ -144,7 +144,7 @@ struct RowSink<kBFloat16> {  // word = (comp << 8 | nonComp) >> 1 | (nonComp & 1
   __device__ __forceinline__ void store(uint32_t row, uint32_t e0, uint32_t r) const {
     const uint32_t lo = (r << 16) | e0;                                   // [sym][nc][0000 pdf]
     const uint32_t v = __builtin_amdgcn_alignbit(r, lo, 1);               // (lo >> 1) | (r << 31)
-    out[row * 32u] = (uint16_t)(v >> 16);                                 // [sign][exp][mant7]
+    streamStore<DGPU_NT_DEC_STORES != 0>(&out[row * 32u], (uint16_t)(v >> 16));                    // [sign][exp][mant7]
   }
 };
 
@@ -163,7 +163,7 @@ struct RowSink<kFloat32> {  // rotr32(comp << 24 | nonComp24, 1)
   }
   __device__ __forceinline__ void store(uint32_t row, uint32_t e0, uint32_t r) const {
     const uint32_t v = (e0 & 0xff000000u) | r;
-    out[row * 32u] = __builtin_amdgcn_alignbit(v, v, 1);
+    streamStore<DGPU_NT_DEC_STORES != 0>(&out[row * 32u], (uint32_t)__builtin_amdgcn_alignbit(v, v, 1));
   }
 };
 

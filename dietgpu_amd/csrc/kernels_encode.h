@@ -52,12 +52,33 @@ namespace dgpu {
 // most P bits each plus the 16-bit start/end slack and the sub-bit rounding
 // slop of the state update => 8 * P + 1 words per lane.
 __host__ __device__ constexpr uint32_t encStageWords(int P) { return 32u * (8u * (uint32_t)P + 1u); }
-__host__ __device__ constexpr uint32_t encLdsBytes(int P) {
-  return 4096u                                   // packed symbol table
-      + 128u                                     // tile bookkeeping
-      + kBlocksPerTile * encStageWords(P) * 2u   // bitstream stage per half-wave
-      + kBlocksPerTile * 512u                    // symbol ring, 16 rows per half-wave
-      + 512u;                                    // scratch slots of non-emitting lanes
+
+// Two stage policies (template parameter kSpill of the kernel):
+//   * kSpill = false: the LDS stage of a block holds its worst case
+//     (encStageWords).  ~50 KiB of LDS per workgroup => 3 workgroups per CU.
+//   * kSpill = true: the stage holds kSpillStageWords.  Every kFlushRows rows
+//     the wave checks whether the next kFlushRows rows could overflow it (a row
+//     emits at most 32 words per block); if so the stage's whole 16-byte
+//     vectors are flushed to a per-workgroup spill slot in temp memory and read
+//     back at copy-out.  ~25 KiB of LDS => 6 workgroups per CU, which is what
+//     keeps the SIMDs issuing row steps while other tiles sit in their
+//     look-back / copy-out phases.  Exponent streams (2-4 bits per symbol) never
+//     reach the flush threshold of 3 bits/symbol averaged over a block; the
+//     spill path is the safety net for incompressible inputs, not the fast path.
+constexpr uint32_t kSpillStageWords = 1024;
+constexpr uint32_t kFlushRows = 8;
+// words of spill slot per block: the worst case of a block (whole vectors)
+__host__ __device__ constexpr uint32_t encSpillSlotWords(int P) { return roundUp(encStageWords(P), 8u) + 8u; }
+
+__host__ __device__ constexpr uint32_t encStageCap(int P, bool spill) {
+  return spill ? kSpillStageWords : encStageWords(P);
+}
+__host__ __device__ constexpr uint32_t encLdsBytes(int P, bool spill) {
+  return 4096u                                       // packed symbol table
+      + 128u                                         // tile bookkeeping
+      + kBlocksPerTile * encStageCap(P, spill) * 2u  // bitstream stage per half-wave
+      + kBlocksPerTile * 512u                        // symbol ring, 16 rows per half-wave
+      + 512u;                                        // scratch slots of non-emitting lanes
 }
 
 constexpr uint64_t kDescAggregate = 1ull << 62;
@@ -70,8 +91,10 @@ struct EncodeArgs {
   const uint4* encTable;     // [B][256] from k_normalize
   uint32_t maxTiles;         // tiles per element the ticket space is laid out for
   uint32_t numInBatch;       // B
+  uint32_t numTickets;       // B * maxTiles
   uint64_t* tileDesc;        // [B][maxTiles], zeroed before launch
   uint32_t* ticket;          // zeroed before launch
+  uint16_t* spill;           // [gridDim.x][kBlocksPerTile][encSpillSlotWords(P)] (kSpill kernels only)
   uint32_t* outSize;         // [B] nullable
   uint32_t useChecksum;      // float header only
   const uint32_t* checksum;  // [B] nullable (float header only)
@@ -126,7 +149,7 @@ struct ChunkSource<0> {  // raw bytes: the symbols are the input
   }
   __device__ __forceinline__ Raw load(uint32_t c, uint32_t hl) const {
     Raw r;
-    r.v = ((const uint4*)in)[c * 32u + hl];
+    r.v = streamLoad<DGPU_NT_ENC_LOADS != 0>(&((const uint4*)in)[c * 32u + hl]);
     return r;
   }
   __device__ __forceinline__ uint4 consume(const Raw& r, uint32_t, uint32_t) const { return r.v; }
@@ -151,8 +174,8 @@ struct ChunkSource16 {
   __device__ __forceinline__ Raw load(uint32_t c, uint32_t hl) const {
     const uint4* p = (const uint4*)(in + c * 512u + hl * 16u);
     Raw r;
-    r.a = p[0];
-    r.b = p[1];
+    r.a = streamLoad<DGPU_NT_ENC_LOADS != 0>(&p[0]);
+    r.b = streamLoad<DGPU_NT_ENC_LOADS != 0>(&p[1]);
     return r;
   }
   // FloatTypeInfo<FT>::split (GpuFloatUtils.cuh:111-115, 141-147) on packed pairs
@@ -181,7 +204,7 @@ struct ChunkSource16 {
         rest[j] = packBytes02(q[2 * j + 1], q[2 * j]);
       }
     }
-    ((uint4*)(nc + c * 512u))[hl] = make_uint4(rest[0], rest[1], rest[2], rest[3]);
+    streamStore<DGPU_NT_ENC_STORES != 0>(&((uint4*)(nc + c * 512u))[hl], make_uint4(rest[0], rest[1], rest[2], rest[3]));
     return make_uint4(comp[0], comp[1], comp[2], comp[3]);
   }
   __device__ __forceinline__ uint32_t symbolAt(uint32_t i) const {
@@ -218,7 +241,7 @@ struct ChunkSource<kFloat32> {  // 4-byte words: comp byte + 24 non-comp bits (u
     const uint4* p = (const uint4*)(in + c * 512u + hl * 16u);
     Raw r;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r.v[j] = p[j];
+    for (int j = 0; j < 4; ++j) r.v[j] = streamLoad<DGPU_NT_ENC_LOADS != 0>(&p[j]);
     return r;
   }
   // FloatTypeInfo<kFloat32>::split (GpuFloatUtils.cuh:181-185): v = rotl(w, 1)
@@ -243,9 +266,9 @@ struct ChunkSource<kFloat32> {  // 4-byte words: comp byte + 24 non-comp bits (u
       lo[2 * j + 1] = __builtin_amdgcn_perm(v[4 * j + 3], v[4 * j + 2], 0x05040100u);
     }
     uint4* p2 = (uint4*)(nc2 + c * 512u + hl * 16u);
-    p2[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-    p2[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
-    ((uint4*)(nc1 + c * 512u))[hl] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    streamStore<DGPU_NT_ENC_STORES != 0>(&p2[0], make_uint4(lo[0], lo[1], lo[2], lo[3]));
+    streamStore<DGPU_NT_ENC_STORES != 0>(&p2[1], make_uint4(lo[4], lo[5], lo[6], lo[7]));
+    streamStore<DGPU_NT_ENC_STORES != 0>(&((uint4*)(nc1 + c * 512u))[hl], make_uint4(hi[0], hi[1], hi[2], hi[3]));
     return make_uint4(comp[0], comp[1], comp[2], comp[3]);
   }
   __device__ __forceinline__ uint32_t symbolAt(uint32_t i) const {
@@ -258,7 +281,7 @@ struct ChunkSource<kFloat32> {  // 4-byte words: comp byte + 24 non-comp bits (u
 };
 
 // ---------------------------------------------------------------------------
-template <int P, uint32_t FT, bool kFull>
+template <int P, uint32_t FT, bool kFull, bool kSpill>
 __device__ __forceinline__ uint32_t encodeRows(
     const ChunkSource<FT>& src,
     uint32_t n,                           // symbols in this half's block (0 = idle half)
@@ -270,10 +293,37 @@ __device__ __forceinline__ uint32_t encodeRows(
     uint8_t* __restrict__ ring,           // LDS, this half's 512-byte symbol ring
     uint32_t hl,
     bool upper,
+    uint16_t* __restrict__ spill,         // this half's spill slot (kSpill only)
+    uint32_t& spilledOut,                 // words flushed to it (multiple of 8)
     uint32_t& stateOut) {
   const uint32_t laneMaskLt = (1u << hl) - 1u;
   uint32_t state = kStartState;
   uint32_t outOff = 0;
+  uint32_t spilled = 0;
+
+  // Called every kFlushRows rows: make room for the next kFlushRows rows.
+  auto makeRoom = [&]() {
+    if (!kSpill) return;
+    const uint32_t o0 = __builtin_amdgcn_readlane(outOff, 0);
+    const uint32_t o1 = __builtin_amdgcn_readlane(outOff, 32);
+    if ((o0 > o1 ? o0 : o1) + kFlushRows * 32u <= kSpillStageWords) return;  // wave-uniform
+    // whole 16-byte vectors go to the spill slot, the (< 8 word) rest moves to the front
+    uint32_t nvec = outOff >> 3;
+    // cannot happen with a table made from this data's histogram; keeps a
+    // mismatching caller-supplied histogram from writing past the slot
+    if (spilled + nvec * 8u > encSpillSlotWords(P)) nvec = 0;
+    uint4* dst = (uint4*)(spill + spilled);
+    for (uint32_t i = hl; i < nvec; i += 32u) {
+      const u32x4e v = *(const LdsU4e*)(uintptr_t)(stageBase + 16u * i);
+      dst[i] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+    const uint32_t rem = outOff & 7u;
+    uint16_t t = 0;
+    if (hl < rem) t = *(const LdsU16e*)(uintptr_t)(stageBase + 2u * (nvec * 8u + hl));
+    if (hl < rem) *(LdsU16e*)(uintptr_t)(stageBase + 2u * hl) = t;
+    spilled += nvec * 8u;
+    outOff = rem;
+  };
 
   // Generic step (partial blocks): predicated, emission under a branch.
   auto step = [&](const uint4 e, bool valid) {
@@ -333,6 +383,7 @@ __device__ __forceinline__ uint32_t encodeRows(
       for (int r = 0; r < kAhead; ++r) e[r] = ldsTableEntry(toff[r]);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+        if (r % kFlushRows == 0) makeRoom();
         const uint4 cur_e = e[r % kAhead];
         if (r + kAhead < 16) e[r % kAhead] = ldsTableEntry(toff[r + kAhead]);
         stepFull(cur_e);
@@ -341,26 +392,32 @@ __device__ __forceinline__ uint32_t encodeRows(
   } else {
 #pragma unroll 1
     for (uint32_t row = 0; row < maxRows; ++row) {
+      if (row % kFlushRows == 0) makeRoom();
       const uint32_t i = row * 32u + hl;
       const bool valid = i < n;
       const uint32_t sym = valid ? src.symbolAt(i) : 0u;
       step(table[sym], valid);
     }
   }
+  // The copy-out reads the slot back through other lanes of this wave, after two
+  // workgroup barriers: workgroup-scope ordering is all that is needed (the
+  // waves of a workgroup share their CU's L1), no L2 write-back.
+  spilledOut = spilled;
   stateOut = state;
   return outOff;
 }
 
-template <int P, uint32_t FT>
-__global__ __launch_bounds__(256) void k_ans_encode(EncodeArgs a) {
+template <int P, uint32_t FT, bool kSpill>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_ans_encode(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  constexpr uint32_t kCap = encStageCap(P, kSpill);
   // bookkeeping sits BELOW the stages so that a stage overrun (only possible
-  // with a caller-supplied histogram that does not match the data) can never
-  // reach it
+  // without spilling, with a caller-supplied histogram that does not match the
+  // data) can never reach it
   uint4* sTable = (uint4*)smem;
   TileShared* sh = (TileShared*)(smem + 4096);
   uint16_t* sStage = (uint16_t*)(smem + 4096 + 128);
-  uint8_t* sRing = smem + 4096 + 128 + kBlocksPerTile * encStageWords(P) * 2u;
+  uint8_t* sRing = smem + 4096 + 128 + kBlocksPerTile * kCap * 2u;
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
@@ -369,168 +426,190 @@ __global__ __launch_bounds__(256) void k_ans_encode(EncodeArgs a) {
   const uint32_t hl = lane & 31u;
   const uint32_t hw = wave * 2u + (upper ? 1u : 0u);
 
-  if (tid == 0) {
-    sh->ticket = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  const uint32_t ticket = sh->ticket;
-#ifdef DGPU_PHASE_TIMING
-  const uint32_t phaseSlot = ticket;
-#endif
-  DGPU_PHASE(0);
-  const uint32_t tile = ticket / a.numInBatch;
-  const uint32_t b = ticket - tile * a.numInBatch;
-
-  const uint32_t size = a.in.size(b);
-  const uint32_t nb = divUp(size, kBlockSize);
-  const uint32_t numTiles = divUp(nb, kBlocksPerTile);
-  if (tile >= numTiles) return;  // uniform for the workgroup
-
-  sTable[tid] = a.encTable[b * kNumSymbols + tid];
-  __syncthreads();
-  DGPU_PHASE(1);
-
-  const uint8_t* in = a.in.ptr(b);
-  uint8_t* archive = a.out.ptr(b);
-  uint8_t* ans = archive + ansOffsetInArchive(FT, size);
-
-  if (FT != 0 && tile == 0) {
-    // GpuFloatHeader (GpuFloatCompress.cuh:325-337) and the zero padding of the
-    // non-comp plane(s) up to 16 bytes
-    if (tid == 0) {
-      FloatHeader h;
-      h.magicAndVersion = (kFloatMagic << 16) | kFloatVersion;
-      h.size = size;
-      h.options = FT | (a.useChecksum ? 0x10u : 0u);
-      h.checksum = (a.useChecksum && a.checksum) ? a.checksum[b] : 0u;
-      *(FloatHeader*)archive = h;
-    }
-    if (FT == kFloat32) {
-      uint16_t* nc2 = (uint16_t*)(archive + 16u);
-      uint8_t* nc1 = archive + 16u + 2u * (size_t)roundUp(size, 8u);
-      if (size + tid < roundUp(size, 8u)) nc2[size + tid] = 0;
-      if (size + tid < roundUp(size, 16u)) nc1[size + tid] = 0;
-    } else {
-      uint8_t* nc = archive + 16u;
-      if (size + tid < roundUp(size, 16u)) nc[size + tid] = 0;
-    }
-  }
-
-  const uint32_t block = tile * kBlocksPerTile + hw;
-  const bool haveBlock = block < nb;
-  uint32_t n = 0;
-  if (haveBlock) {
-    const uint32_t begin = block * kBlockSize;
-    n = size - begin < kBlockSize ? size - begin : kBlockSize;
-  }
-  // wave-uniform: are both halves full blocks (and the input vector-aligned)?
-  const uint32_t firstBlockOfWave = tile * kBlocksPerTile + wave * 2u;
-  const bool waveFull = (uint64_t)(firstBlockOfWave + 2u) * kBlockSize <= (uint64_t)size &&
-      (((uintptr_t)in & 15u) == 0);
-
-  ChunkSource<FT> src;
-  src.init(in, archive, size, block);
-
-  uint16_t* stage = sStage + hw * encStageWords(P);
+  uint16_t* stage = sStage + hw * kCap;
   const uint32_t stageLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)stage;
   const uint32_t tableLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)sTable;
   // per-lane scratch slot for non-emitting lanes (512 bytes after the rings)
   const uint32_t dummyLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(sRing + kBlocksPerTile * 512u) + tid * 2u;
-  uint32_t state;
-  uint32_t words;
-  if (waveFull) {
-    words = encodeRows<P, FT, true>(src, n, kRowsPerBlock, sTable, tableLds, stageLds, dummyLds, sRing + hw * 512u, hl, upper, state);
-  } else {
-    // rows needed by the larger of the two halves (uniform)
-    uint32_t nA = 0;
-    if (firstBlockOfWave < nb) {
-      uint32_t beginA = firstBlockOfWave * kBlockSize;
-      nA = size - beginA < kBlockSize ? size - beginA : kBlockSize;  // first half is never smaller than the second
+  uint16_t* spillSlot = kSpill ? a.spill + ((size_t)blockIdx.x * kBlocksPerTile + hw) * encSpillSlotWords(P) : nullptr;
+
+  // Persistent workgroup: tiles are drawn from the ticket counter until it runs out.
+  for (;;) {
+    if (tid == 0) {
+      sh->ticket = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    words = encodeRows<P, FT, false>(src, n, divUp(nA, 32u), sTable, tableLds, stageLds, dummyLds, nullptr, hl, upper, state);
-  }
+    __syncthreads();
+    const uint32_t ticket = sh->ticket;
+    if (ticket >= a.numTickets) break;  // uniform for the workgroup
+#ifdef DGPU_PHASE_TIMING
+    const uint32_t phaseSlot = ticket;
+#endif
+    DGPU_PHASE(0);
+#ifdef DGPU_PHASE_TIMING
+    if (threadIdx.x == 0 && g_phaseBuf) g_phaseBuf[(size_t)phaseSlot * 8 + 7] = blockIdx.x;
+#endif
+    const uint32_t tile = ticket / a.numInBatch;
+    const uint32_t b = ticket - tile * a.numInBatch;
 
-  DGPU_PHASE(2);
-  if (haveBlock) {
-    // final lane states, 128 contiguous bytes per block (GpuANSEncode.cuh:207, :584-590)
-    ((uint32_t*)(ans + ansStatesOffset()))[block * 32u + hl] = state;
-    // zero the pad up to the 16-byte boundary
-    const uint32_t padded = roundUp(words, kBlockAlignWords);
-    if (words + hl < padded) stage[words + hl] = 0;
-  }
-  words = words < encStageWords(P) ? words : encStageWords(P);
-  if (hl == 0) sh->words[hw] = haveBlock ? words : 0u;
-  __syncthreads();
-  DGPU_PHASE(3);
-
-  if (wave == 0) {
-    // local exclusive scan of the padded sizes of the tile's 8 blocks
-    uint32_t myPadded = (lane < kBlocksPerTile) ? roundUp(sh->words[lane], kBlockAlignWords) : 0u;
-    uint32_t incl = waveInclusiveScan(myPadded, lane);
-    const uint32_t aggregate = __shfl(incl, kBlocksPerTile - 1, 64);
-    if (lane < kBlocksPerTile) sh->localOff[lane] = incl - myPadded;
-
-    uint64_t* desc = a.tileDesc + (size_t)b * a.maxTiles;
-    if (lane == 0) {
-      __hip_atomic_store(&desc[tile], kDescAggregate | (uint64_t)aggregate, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t size = a.in.size(b);
+    const uint32_t nb = divUp(size, kBlockSize);
+    const uint32_t numTiles = divUp(nb, kBlocksPerTile);
+    if (tile >= numTiles) {  // uniform; nobody reads sh->ticket after the barrier below
+      __syncthreads();
+      continue;
     }
 
-    // decoupled look-back, 64 predecessors per step
-    uint32_t exclusive = 0;
-    int base = (int)tile - 1;
-    while (base >= 0) {
-      const int idx = base - (int)lane;
-      uint64_t d = kDescInclusive;  // virtual tile -1: inclusive prefix 0
-      if (idx >= 0) {
-        do {
-          d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((d >> 62) == 0) __builtin_amdgcn_s_sleep(1);
-        } while ((d >> 62) == 0);
+    sTable[tid] = a.encTable[b * kNumSymbols + tid];
+    __syncthreads();
+    DGPU_PHASE(1);
+
+    const uint8_t* in = a.in.ptr(b);
+    uint8_t* archive = a.out.ptr(b);
+    uint8_t* ans = archive + ansOffsetInArchive(FT, size);
+
+    if (FT != 0 && tile == 0) {
+      // GpuFloatHeader (GpuFloatCompress.cuh:325-337) and the zero padding of the
+      // non-comp plane(s) up to 16 bytes
+      if (tid == 0) {
+        FloatHeader h;
+        h.magicAndVersion = (kFloatMagic << 16) | kFloatVersion;
+        h.size = size;
+        h.options = FT | (a.useChecksum ? 0x10u : 0u);
+        h.checksum = (a.useChecksum && a.checksum) ? a.checksum[b] : 0u;
+        *(FloatHeader*)archive = h;
       }
-      const uint64_t inclMask = __ballot((d >> 62) == 2);
-      const int firstIncl = inclMask ? (__ffsll((unsigned long long)inclMask) - 1) : 64;
-      const uint32_t v = ((int)lane <= firstIncl) ? (uint32_t)(d & kDescValueMask) : 0u;
-      exclusive += waveReduceSum(v);
-      if (firstIncl < 64) break;
-      base -= 64;
+      if (FT == kFloat32) {
+        uint16_t* nc2 = (uint16_t*)(archive + 16u);
+        uint8_t* nc1 = archive + 16u + 2u * (size_t)roundUp(size, 8u);
+        if (size + tid < roundUp(size, 8u)) nc2[size + tid] = 0;
+        if (size + tid < roundUp(size, 16u)) nc1[size + tid] = 0;
+      } else {
+        uint8_t* nc = archive + 16u;
+        if (size + tid < roundUp(size, 16u)) nc[size + tid] = 0;
+      }
     }
 
-    const uint32_t inclusive = exclusive + aggregate;
-    if (lane == 0) {
-      __hip_atomic_store(&desc[tile], kDescInclusive | (uint64_t)inclusive, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-      sh->tileBase = exclusive;
-      if (tile == numTiles - 1) {
-        // complete the header (GpuANSEncode.cuh:533-566)
-        ((AnsHeader*)ans)->totalCompressedWords = inclusive;
-        if (a.outSize) {
-          a.outSize[b] = ansOffsetInArchive(FT, size) + ansOverhead(nb) + 2u * inclusive;
+    const uint32_t block = tile * kBlocksPerTile + hw;
+    const bool haveBlock = block < nb;
+    uint32_t n = 0;
+    if (haveBlock) {
+      const uint32_t begin = block * kBlockSize;
+      n = size - begin < kBlockSize ? size - begin : kBlockSize;
+    }
+    // wave-uniform: are both halves full blocks (and the input vector-aligned)?
+    const uint32_t firstBlockOfWave = tile * kBlocksPerTile + wave * 2u;
+    const bool waveFull = (uint64_t)(firstBlockOfWave + 2u) * kBlockSize <= (uint64_t)size &&
+        (((uintptr_t)in & 15u) == 0);
+
+    ChunkSource<FT> src;
+    src.init(in, archive, size, block);
+
+    uint32_t state;
+    uint32_t words;        // words left in the LDS stage
+    uint32_t spilled = 0;  // words already in the spill slot
+    if (waveFull) {
+      words = encodeRows<P, FT, true, kSpill>(src, n, kRowsPerBlock, sTable, tableLds, stageLds, dummyLds,
+                                              sRing + hw * 512u, hl, upper, spillSlot, spilled, state);
+    } else {
+      // rows needed by the larger of the two halves (uniform)
+      uint32_t nA = 0;
+      if (firstBlockOfWave < nb) {
+        uint32_t beginA = firstBlockOfWave * kBlockSize;
+        nA = size - beginA < kBlockSize ? size - beginA : kBlockSize;  // first half is never smaller than the second
+      }
+      words = encodeRows<P, FT, false, kSpill>(src, n, divUp(nA, 32u), sTable, tableLds, stageLds, dummyLds,
+                                               nullptr, hl, upper, spillSlot, spilled, state);
+    }
+
+    DGPU_PHASE(2);
+    if (!kSpill) words = words < kCap ? words : kCap;
+    if (haveBlock) {
+      // final lane states, 128 contiguous bytes per block (GpuANSEncode.cuh:207, :584-590)
+      ((uint32_t*)(ans + ansStatesOffset()))[block * 32u + hl] = state;
+      // zero the pad up to the 16-byte boundary (the spilled part is whole vectors)
+      const uint32_t padded = roundUp(words, kBlockAlignWords);
+      if (words + hl < padded) stage[words + hl] = 0;
+    }
+    if (hl == 0) sh->words[hw] = haveBlock ? spilled + words : 0u;
+    __syncthreads();
+    DGPU_PHASE(3);
+
+    if (wave == 0) {
+      // local exclusive scan of the padded sizes of the tile's 8 blocks
+      uint32_t myPadded = (lane < kBlocksPerTile) ? roundUp(sh->words[lane], kBlockAlignWords) : 0u;
+      uint32_t incl = waveInclusiveScan(myPadded, lane);
+      const uint32_t aggregate = __shfl(incl, kBlocksPerTile - 1, 64);
+      if (lane < kBlocksPerTile) sh->localOff[lane] = incl - myPadded;
+
+      uint64_t* desc = a.tileDesc + (size_t)b * a.maxTiles;
+      if (lane == 0) {
+        __hip_atomic_store(&desc[tile], kDescAggregate | (uint64_t)aggregate, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+
+      // decoupled look-back, 64 predecessors per step
+      uint32_t exclusive = 0;
+      int base = (int)tile - 1;
+      while (base >= 0) {
+        const int idx = base - (int)lane;
+        uint64_t d = kDescInclusive;  // virtual tile -1: inclusive prefix 0
+        if (idx >= 0) {
+          do {
+            d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((d >> 62) == 0) __builtin_amdgcn_s_sleep(1);
+          } while ((d >> 62) == 0);
+        }
+        const uint64_t inclMask = __ballot((d >> 62) == 2);
+        const int firstIncl = inclMask ? (__ffsll((unsigned long long)inclMask) - 1) : 64;
+        const uint32_t v = ((int)lane <= firstIncl) ? (uint32_t)(d & kDescValueMask) : 0u;
+        exclusive += waveReduceSum(v);
+        if (firstIncl < 64) break;
+        base -= 64;
+      }
+
+      const uint32_t inclusive = exclusive + aggregate;
+      if (lane == 0) {
+        __hip_atomic_store(&desc[tile], kDescInclusive | (uint64_t)inclusive, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        sh->tileBase = exclusive;
+        if (tile == numTiles - 1) {
+          // complete the header (GpuANSEncode.cuh:533-566)
+          ((AnsHeader*)ans)->totalCompressedWords = inclusive;
+          if (a.outSize) {
+            a.outSize[b] = ansOffsetInArchive(FT, size) + ansOverhead(nb) + 2u * inclusive;
+          }
         }
       }
+      // per-block word counts and start offsets (GpuANSEncode.cuh:595-608)
+      uint2* blockWords = (uint2*)(ans + ansBlockWordsOffset(nb));
+      const uint32_t blk = tile * kBlocksPerTile + lane;
+      if (lane < kBlocksPerTile && blk < nb) {
+        const uint32_t begin = blk * kBlockSize;
+        const uint32_t bn = size - begin < kBlockSize ? size - begin : kBlockSize;
+        blockWords[blk] = make_uint2((bn << 16) | sh->words[lane], exclusive + (incl - myPadded));
+      }
+      if (tile == numTiles - 1 && (nb & 1u) && lane == kBlocksPerTile) {
+        blockWords[nb] = make_uint2(0u, 0u);  // alignment pad entry
+      }
     }
-    // per-block word counts and start offsets (GpuANSEncode.cuh:595-608)
-    uint2* blockWords = (uint2*)(ans + ansBlockWordsOffset(nb));
-    const uint32_t blk = tile * kBlocksPerTile + lane;
-    if (lane < kBlocksPerTile && blk < nb) {
-      const uint32_t begin = blk * kBlockSize;
-      const uint32_t bn = size - begin < kBlockSize ? size - begin : kBlockSize;
-      blockWords[blk] = make_uint2((bn << 16) | sh->words[lane], exclusive + (incl - myPadded));
-    }
-    if (tile == numTiles - 1 && (nb & 1u) && lane == kBlocksPerTile) {
-      blockWords[nb] = make_uint2(0u, 0u);  // alignment pad entry
-    }
-  }
-  __syncthreads();
-  DGPU_PHASE(4);
+    __syncthreads();
+    DGPU_PHASE(4);
 
-  if (haveBlock) {
-    const uint32_t vecs = roundUp(words, kBlockAlignWords) / kBlockAlignWords;
-    const uint4* s4 = (const uint4*)stage;
-    uint4* dst = (uint4*)(ans + ansOverhead(nb) + 2u * (size_t)(sh->tileBase + sh->localOff[hw]));
-    for (uint32_t i = hl; i < vecs; i += 32u) dst[i] = s4[i];
+    if (haveBlock) {
+      uint4* dst = (uint4*)(ans + ansOverhead(nb) + 2u * (size_t)(sh->tileBase + sh->localOff[hw]));
+      if (kSpill && spilled) {
+        // spilled vectors first (written by this wave before the barriers above)
+        const uint4* sp = (const uint4*)spillSlot;
+        const uint32_t sv = spilled / kBlockAlignWords;
+        for (uint32_t i = hl; i < sv; i += 32u) streamStore<DGPU_NT_ENC_STORES != 0>(&dst[i], sp[i]);
+        dst += sv;
+      }
+      const uint32_t vecs = roundUp(words, kBlockAlignWords) / kBlockAlignWords;
+      const uint4* s4 = (const uint4*)stage;
+      for (uint32_t i = hl; i < vecs; i += 32u) streamStore<DGPU_NT_ENC_STORES != 0>(&dst[i], s4[i]);
+    }
+    DGPU_PHASE(5);
   }
-  DGPU_PHASE(5);
 }
 
 // ---------------------------------------------------------------------------
@@ -539,7 +618,7 @@ __global__ __launch_bounds__(256) void k_ans_encode(EncodeArgs a) {
 // GpuFloatCompress.cuh:144, 352-364).  grid = (xBlocks, B), 256 threads;
 // hist must be zeroed first.
 template <uint32_t FT>
-__global__ __launch_bounds__(256) void k_float_histogram(BatchView in, uint32_t* __restrict__ hist) {
+__global__ __launch_bounds__(256) void k_float_histogram(BatchView in, uint32_t* __restrict__ hist, uint32_t partial) {
   __shared__ uint32_t bins[kHistBlockWords];
   const uint32_t tid = threadIdx.x;
   const uint32_t b = blockIdx.y;
@@ -576,13 +655,13 @@ __global__ __launch_bounds__(256) void k_float_histogram(BatchView in, uint32_t*
   // four 16-byte loads in flight per lane (the kernel is HBM-latency bound otherwise)
   uint32_t v = blockIdx.x * 256u + tid;
   for (; v + 3u * stride < numVec; v += 4u * stride) {
-    const uint4 x0 = pv[v], x1 = pv[v + stride], x2 = pv[v + 2u * stride], x3 = pv[v + 3u * stride];
+    const uint4 x0 = streamLoad<DGPU_NT_HIST_LOADS != 0>(&pv[v]), x1 = streamLoad<DGPU_NT_HIST_LOADS != 0>(&pv[v + stride]), x2 = streamLoad<DGPU_NT_HIST_LOADS != 0>(&pv[v + 2u * stride]), x3 = streamLoad<DGPU_NT_HIST_LOADS != 0>(&pv[v + 3u * stride]);
     addVec(x0);
     addVec(x1);
     addVec(x2);
     addVec(x3);
   }
-  for (; v < numVec; v += stride) addVec(pv[v]);
+  for (; v < numVec; v += stride) addVec(streamLoad<DGPU_NT_HIST_LOADS != 0>(&pv[v]));
 
   // tail (and the whole element when the input is not 16-byte aligned)
   for (uint32_t i = numVec * kWordsPerVec + blockIdx.x * 256u + tid; i < n; i += stride) {
@@ -592,8 +671,7 @@ __global__ __launch_bounds__(256) void k_float_histogram(BatchView in, uint32_t*
     histAdd(myBins, c);
   }
   __syncthreads();
-  const uint32_t sum = histFold(bins, tid);
-  if (sum) atomicAdd(&hist[b * kNumSymbols + tid], sum);
+  histStore(hist, partial, b, tid, histFold(bins, tid));
 }
 
 }  // namespace dgpu

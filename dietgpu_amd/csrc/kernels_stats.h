@@ -75,7 +75,18 @@ __device__ __forceinline__ void histAdd4(uint32_t* mine, uint32_t x) {
   histAdd(mine, x >> 24);
 }
 
-__global__ __launch_bounds__(256) void k_histogram(BatchView in, uint32_t* __restrict__ hist) {
+// `partial` != 0: this workgroup stores its 256 totals to hist[(b * gridDim.x + blockIdx.x) * 256 + bin]
+// (no atomics, no zero-initialisation needed; k_normalize adds the parts up).  Otherwise it adds
+// them atomically into hist[b][256], which must have been zeroed.
+__device__ __forceinline__ void histStore(uint32_t* __restrict__ hist, uint32_t partial, uint32_t b, uint32_t tid, uint32_t sum) {
+  if (partial) {
+    hist[((size_t)b * gridDim.x + blockIdx.x) * kNumSymbols + tid] = sum;
+  } else if (sum) {
+    atomicAdd(&hist[b * kNumSymbols + tid], sum);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_histogram(BatchView in, uint32_t* __restrict__ hist, uint32_t partial) {
   __shared__ uint32_t bins[kHistBlockWords];
   const uint32_t tid = threadIdx.x;
   const uint32_t b = blockIdx.y;
@@ -99,14 +110,14 @@ __global__ __launch_bounds__(256) void k_histogram(BatchView in, uint32_t* __res
   const uint32_t stride = gridDim.x * 256u;
   uint32_t i = blockIdx.x * 256u + tid;
   for (; i + 3u * stride < numVec; i += 4u * stride) {
-    const uint4 v0 = pv[i], v1 = pv[i + stride], v2 = pv[i + 2u * stride], v3 = pv[i + 3u * stride];
+    const uint4 v0 = streamLoad<DGPU_NT_HIST_LOADS != 0>(&pv[i]), v1 = streamLoad<DGPU_NT_HIST_LOADS != 0>(&pv[i + stride]), v2 = streamLoad<DGPU_NT_HIST_LOADS != 0>(&pv[i + 2u * stride]), v3 = streamLoad<DGPU_NT_HIST_LOADS != 0>(&pv[i + 3u * stride]);
     histAdd4(myBins, v0.x); histAdd4(myBins, v0.y); histAdd4(myBins, v0.z); histAdd4(myBins, v0.w);
     histAdd4(myBins, v1.x); histAdd4(myBins, v1.y); histAdd4(myBins, v1.z); histAdd4(myBins, v1.w);
     histAdd4(myBins, v2.x); histAdd4(myBins, v2.y); histAdd4(myBins, v2.z); histAdd4(myBins, v2.w);
     histAdd4(myBins, v3.x); histAdd4(myBins, v3.y); histAdd4(myBins, v3.z); histAdd4(myBins, v3.w);
   }
   for (; i < numVec; i += stride) {
-    const uint4 v = pv[i];
+    const uint4 v = streamLoad<DGPU_NT_HIST_LOADS != 0>(&pv[i]);
     histAdd4(myBins, v.x);
     histAdd4(myBins, v.y);
     histAdd4(myBins, v.z);
@@ -119,8 +130,7 @@ __global__ __launch_bounds__(256) void k_histogram(BatchView in, uint32_t* __res
   }
   __syncthreads();
 
-  const uint32_t sum = histFold(bins, tid);
-  if (sum) atomicAdd(&hist[b * kNumSymbols + tid], sum);
+  histStore(hist, partial, b, tid, histFold(bins, tid));
 }
 
 // ---------------------------------------------------------------------------
@@ -182,7 +192,8 @@ __global__ __launch_bounds__(256) void k_checksum(
 // ranks); the block scan by wave64 shuffles.
 struct NormalizeArgs {
   BatchView sizes;           // only size(b) is used
-  const uint32_t* hist;      // [B][256]
+  const uint32_t* hist;      // [B][histParts][256]: per-workgroup partial histograms, summed here
+  uint32_t histParts;
   int probBits;
   uint4* encTable;           // [B][256] nullable
   uint4* refTable;           // [B][256] nullable
@@ -193,6 +204,10 @@ struct NormalizeArgs {
   const uint32_t* checksum;  // [B] nullable
   uint32_t* outSize;         // [B] nullable
   uint32_t floatUseChecksum; // float archives: checksum flag for the header of an EMPTY element
+  // encode hand-off state cleared here for the encode kernel that follows on the stream
+  uint64_t* tileDesc;        // [B][maxTiles] nullable
+  uint32_t maxTiles;
+  uint32_t* ticket;          // nullable
 };
 
 __global__ __launch_bounds__(256) void k_normalize(NormalizeArgs a) {
@@ -214,8 +229,14 @@ __global__ __launch_bounds__(256) void k_normalize(NormalizeArgs a) {
 
   uint32_t pdf = 0, cdf = 0, magic = 0, shift = 0;
 
+  if (a.tileDesc) {
+    for (uint32_t i = tid; i < a.maxTiles; i += 256u) a.tileDesc[(size_t)b * a.maxTiles + i] = 0;
+    if (b == 0 && tid == 0) *a.ticket = 0;
+  }
+
   if (total != 0) {
-    const uint32_t count = a.hist[b * kNumSymbols + tid];
+    uint32_t count = 0;
+    for (uint32_t x = 0; x < a.histParts; ++x) count += a.hist[((size_t)b * a.histParts + x) * kNumSymbols + tid];
     // :215  qProb = kProbWeight * ((float)count / (float)totalNum), truncated.
     // Explicit round-to-nearest divide and multiply: no fma contraction, no
     // approximate reciprocal.

@@ -39,10 +39,13 @@ def test_size_queries_match_oracle():
             assert L.dgpu_float_max_compressed_size(ft, n) == O.float_max_compressed_size(ft, n)
     assert L.dgpu_ans_max_compressed_size(1 << 20) == 1868320
     assert L.dgpu_float_max_compressed_size(2, 524288) == 1737264
-    # temp memory of the 256 x 1 MiB configs: a few MiB (tables, tile descriptors), not the
-    # reference's 328 MiB block scratch + 128 MiB exponent plane
-    assert L.dgpu_float_compress_temp_bytes(2, 256, 524288) < 4 * 1024 * 1024
-    assert L.dgpu_ans_encode_temp_bytes(256, 1 << 20) < 4 * 1024 * 1024
+    # temp memory of the 256 x 1 MiB configs: ~10 MiB (partial histograms, tables, tile
+    # descriptors) + for floats the spill slots of the resident encoder workgroups (~70 MiB,
+    # independent of the batch size), not the reference's 328 MiB block scratch + 128 MiB
+    # exponent plane
+    assert L.dgpu_float_compress_temp_bytes(2, 256, 524288) < 96 * 1024 * 1024
+    assert L.dgpu_float_compress_temp_bytes(2, 1, 1 << 30) < 96 * 1024 * 1024 + (1 << 30) // 1000
+    assert L.dgpu_ans_encode_temp_bytes(256, 1 << 20) < 12 * 1024 * 1024
 
 
 def test_ops_argument_validation_without_gpu():

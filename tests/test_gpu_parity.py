@@ -335,6 +335,38 @@ def test_float_batch(dg, ft, prob_bits):
 
 
 @pytest.mark.parametrize("ft", [O.FLOAT16, O.BFLOAT16, O.FLOAT32])
+@pytest.mark.parametrize("prob_bits", [9, 10, 11])
+def test_float_incompressible_exponents(dg, ft, prob_bits):
+    # random bit patterns: ~8 bits of entropy per exponent byte, so every block overflows the
+    # float encoder's small LDS stage and goes through its spill path (full and partial
+    # blocks, several tiles, ragged batch); one element mixes both regimes
+    rng = np.random.default_rng(1000 + ft * 10 + prob_bits)
+    dt = np.uint32 if ft == O.FLOAT32 else np.uint16
+    hi = 1 << (32 if ft == O.FLOAT32 else 16)
+    ns = [4096 * 40, 4096 * 9 + 1234, 777, 4096 * 16, 4096 * 33 + 5]
+    ws = [rng.integers(0, hi, n, dtype=np.uint64).astype(dt) for n in ns]
+    mixed = refgen.generate_floats(ft, 4096 * 24)
+    mixed[4096 * 5 : 4096 * 9] = rng.integers(0, hi, 4096 * 4, dtype=np.uint64).astype(dt)
+    ws.append(mixed)
+    ts = [words_to_tensor(ft, w) for w in ws]
+    comp, sizes, _ = dg.compress_data(True, ts, False, prob_bits=prob_bits)
+    hs = sizes.cpu().numpy()
+    hc = comp.cpu().numpy()
+    arch = []
+    for i, w in enumerate(ws):
+        want = O.float_compress(ft, w, prob_bits)
+        assert hs[i] == want.size and (hc[i, : hs[i]] == want).all(), (ft, prob_bits, i)
+        arch.append(comp[i, : hs[i]].clone())
+    outs = [torch.empty_like(t) for t in ts]
+    status = torch.zeros((len(ts),), dtype=torch.uint8, device=DEV)
+    osz = torch.zeros((len(ts),), dtype=torch.int32, device=DEV)
+    dg.decompress_data(True, arch, outs, False, None, status, osz, prob_bits=prob_bits)
+    assert status.cpu().numpy().all()
+    for w, o in zip(ws, outs):
+        assert (tensor_to_words(ft, o) == w).all()
+
+
+@pytest.mark.parametrize("ft", [O.FLOAT16, O.BFLOAT16, O.FLOAT32])
 def test_float_unaligned_io(dg, ft):
     # inputs / outputs that are only float-word aligned (scalar paths)
     n = 20000

@@ -46,4 +46,20 @@ for k, n in enumerate(names):
     print(f"  {n:16s} mean {d.mean():9.0f}  p50 {np.median(d):9.0f}  p95 {np.percentile(d, 95):9.0f} cycles (s_memtime @100MHz? ticks)")
 tot = (t[:, 5] - t[:, 0]).astype(np.float64)
 print(f"  {'total':16s} mean {tot.mean():9.0f}")
-print("  span of kernel (max end - min start):", int(t[:, 5].max() - t[:, 0].min()))
+span = int(t[:, 5].max() - t[:, 0].min())
+print("  span of kernel (max end - min start):", span)
+# per-workgroup timelines (slot 7 = blockIdx.x): idle time between consecutive tiles, start skew
+wg = t[:, 7]
+t0 = t[:, 0].min()
+gaps, firsts, lasts, counts = [], [], [], []
+for w in np.unique(wg):
+    r = t[wg == w]
+    r = r[np.argsort(r[:, 0])]
+    firsts.append(r[0, 0] - t0)
+    lasts.append(r[-1, 5] - t0)
+    counts.append(len(r))
+    gaps += list(r[1:, 0] - r[:-1, 5])
+print(f"  workgroups {len(firsts)}  tiles/WG mean {np.mean(counts):.2f} min {min(counts)} max {max(counts)}")
+print(f"  first tile start: mean {np.mean(firsts):.0f} max {np.max(firsts):.0f};  last tile end: mean {np.mean(lasts):.0f} min {np.min(lasts):.0f} max {np.max(lasts):.0f}")
+if gaps:
+    print(f"  gap between tiles of a WG: mean {np.mean(gaps):.0f} p95 {np.percentile(gaps, 95):.0f}")

@@ -3,6 +3,7 @@
 
   tools/rocpd_summary.py stats  <db>            kernel-trace --stats style table
   tools/rocpd_summary.py pmc    <db> [<db>...]  per-kernel mean of each collected counter
+  tools/rocpd_summary.py timeline <db> [n]      last n kernels / copies in start order with gaps
 """
 import re
 import sqlite3
@@ -59,9 +60,27 @@ def pmcrows(dbs, only="dgpu::"):
             print("    %-28s %16.1f   (dispatch %.1f us)" % (c, d[c][0], d[c][1] / 1e3))
 
 
+def timeline(db, n=40):
+    con = sqlite3.connect(db)
+    ev = [(s, e, short(nm)) for nm, s, e in con.execute("select name, start, end from kernels")]
+    try:
+        ev += [(s, e, "COPY " + str(nm)) for nm, s, e in con.execute("select name, start, end from memory_copies")]
+    except sqlite3.Error:
+        pass
+    ev.sort()
+    ev = ev[-n:]
+    t0, prev = ev[0][0], ev[0][0]
+    print("%10s %9s %9s  %s" % ("start_us", "dur_us", "gap_us", "what"))
+    for s, e, nm in ev:
+        print("%10.1f %9.1f %9.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev) / 1e3, nm))
+        prev = max(prev, e)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "timeline":
+        timeline(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 40)
     elif sys.argv[1] == "pmcrows":
         pmcrows(sys.argv[2:])
     else:
