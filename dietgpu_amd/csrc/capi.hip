@@ -707,10 +707,6 @@ int decodeImpl(
     out = *strideOut;
   }
 
-  DGPU_ALLOC(lut, uint2, arena, (size_t)B << P);
-  DGPU_LAUNCH("k_decode_table", stream, k_decode_table, dim3(B), dim3(256), 0, stream, in, ft, P, lut);
-  DGPU_HIP(hipGetLastError());
-
   uint32_t* sizesForChecksum = outSize_dev;
   uint8_t* successForChecksum = outSuccess_dev;
   if (useChecksum) {
@@ -730,7 +726,6 @@ int decodeImpl(
     d.in = in;
     d.out = out;
     d.floatType = ft;
-    d.lut = lut;
     d.outSuccess = useChecksum ? successForChecksum : outSuccess_dev;
     d.outSize = useChecksum ? sizesForChecksum : outSize_dev;
     dim3 grid(maxTiles, B);
@@ -893,8 +888,8 @@ size_t dgpu_ans_encode_temp_bytes(uint32_t B, uint32_t maxBytes) {
 
 size_t dgpu_ans_decode_temp_bytes(uint32_t B, uint32_t maxBytes, int probBits) {
   (void)maxBytes;
+  (void)probBits;  // the decode LUT is built in LDS by each workgroup
   size_t t = 0;
-  t += alignUp(((size_t)B << probBits) * 8, kTempAlign);
   t += 3 * alignUp((size_t)B * 8, kTempAlign);  // checksum verification scratch
   return t + kTempAlign;
 }

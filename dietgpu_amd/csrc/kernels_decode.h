@@ -38,60 +38,10 @@ __device__ __forceinline__ const uint8_t* locateAns(const uint8_t* archive, uint
 }
 
 // ---------------------------------------------------------------------------
-// Decode LUT: for x in [0, 2^P) with sym the symbol whose cdf range holds x,
-//   lut[b][x] = { pdf[sym] | sym << 24,  x - cdf[sym] }
-// (the information of packDecodeLookup, GpuANSDecode.cuh:34-41, re-packed so
-// that v_mad_u32_u24 can take word 0 directly: its low 24 bits are the pdf).
-// grid = B, 256 threads; every slot finds its symbol by binary search over the
-// cdf in LDS.
-__global__ __launch_bounds__(256) void k_decode_table(
-    BatchView in, uint32_t floatType, int probBits, uint2* __restrict__ lut) {
-  __shared__ uint32_t sCdf[kNumSymbols];
-  __shared__ uint32_t sPdf[kNumSymbols];
-  __shared__ uint32_t sWave[4];
-  const uint32_t tid = threadIdx.x;
-  const uint32_t lane = tid & 63u;
-  const uint32_t wave = tid >> 6;
-  const uint32_t b = blockIdx.x;
-
-  const uint8_t* ans = locateAns(in.ptr(b), floatType, nullptr);
-  const AnsHeader* h = (const AnsHeader*)ans;
-  if (h->magicAndVersion != ((kAnsMagic << 16) | kAnsVersion)) return;
-  if (h->totalUncompressedWords == 0) return;  // GpuANSDecode.cuh:424-427
-
-  const uint32_t pdf = ((const uint16_t*)(ans + sizeof(AnsHeader)))[tid];
-  uint32_t incl = waveInclusiveScan(pdf, lane);
-  if (lane == 63) sWave[wave] = incl;
-  __syncthreads();
-  uint32_t waveBase = 0;
-  for (uint32_t w = 0; w < wave; ++w) waveBase += sWave[w];
-  sCdf[tid] = waveBase + incl - pdf;
-  sPdf[tid] = pdf;
-  __syncthreads();
-
-  const uint32_t slots = 1u << probBits;
-  uint2* out = lut + (size_t)b * slots;
-  for (uint32_t x = tid; x < slots; x += 256u) {
-    // last symbol s with cdf[s] <= x (zero-pdf symbols share the cdf of their
-    // successor and are skipped by taking the last one)
-    uint32_t lo = 0, hi = kNumSymbols;  // invariant: cdf[lo] <= x, answer in [lo, hi)
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      uint32_t mid = (lo + hi) >> 1;
-      bool le = sCdf[mid] <= x;
-      lo = le ? mid : lo;
-      hi = le ? hi : mid;
-    }
-    out[x] = make_uint2((sPdf[lo] & 0xfffu) | (lo << 24), (x - sCdf[lo]) & 0xfffu);
-  }
-}
-
-// ---------------------------------------------------------------------------
 struct DecodeArgs {
   BatchView in;            // archive pointers
   BatchView out;           // output pointers + capacities (bytes for raw, float words for float)
   uint32_t floatType;      // must equal the template FT
-  const uint2* lut;        // [B][1 << P]
   uint8_t* outSuccess;     // [B] nullable
   uint32_t* outSize;       // [B] nullable
 };
@@ -343,10 +293,38 @@ __global__ __launch_bounds__(kDecThreads) void k_ans_decode(DecodeArgs a) {
   }
   if (!success || tile * kDecBlocksPerTile >= nb) return;
 
+  // Decode LUT, built by the workgroup itself from the archive's pdf table (no
+  // separate table kernel / LUT round trip through HBM):
+  //   lut[x] = { pdf[sym] | sym << 24,  x - cdf[sym] },  sym = symbol whose cdf range holds x
+  // (the information of packDecodeLookup, GpuANSDecode.cuh:34-41, re-packed so
+  // that v_mad_u32_u24 can take word 0 directly: its low 24 bits are the pdf).
+  // Wave 0 scans the 256 pdfs on its own (4 per lane), so one barrier suffices;
+  // the cdf/pdf scratch lives in the ring area, which is not in use yet.
   {
-    const uint4* src = (const uint4*)(a.lut + ((size_t)b << P));
-    uint4* dst = (uint4*)sLut;
-    for (uint32_t i = tid; i < (1u << P) / 2u; i += kDecThreads) dst[i] = src[i];
+    uint32_t* sCdf = (uint32_t*)smem;
+    uint32_t* sPdf = sCdf + kNumSymbols;
+    if (wave == 0) {
+      const uint2 raw = ((const uint2*)(ans + sizeof(AnsHeader)))[lane];  // pdf[4 lane .. 4 lane + 3]
+      const uint32_t p0 = raw.x & 0xffffu, p1 = raw.x >> 16, p2 = raw.y & 0xffffu, p3 = raw.y >> 16;
+      const uint32_t mine = p0 + p1 + p2 + p3;
+      const uint32_t base = waveInclusiveScan(mine, lane) - mine;
+      ((uint4*)sCdf)[lane] = make_uint4(base, base + p0, base + p0 + p1, base + p0 + p1 + p2);
+      ((uint4*)sPdf)[lane] = make_uint4(p0, p1, p2, p3);
+    }
+    __syncthreads();
+    for (uint32_t x = tid; x < (1u << P); x += kDecThreads) {
+      // last symbol s with cdf[s] <= x (zero-pdf symbols share the cdf of their
+      // successor and are skipped by taking the last one)
+      uint32_t lo = 0, hi = kNumSymbols;  // invariant: cdf[lo] <= x, answer in [lo, hi)
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const bool le = sCdf[mid] <= x;
+        lo = le ? mid : lo;
+        hi = le ? hi : mid;
+      }
+      sLut[x] = make_uint2((sPdf[lo] & 0xfffu) | (lo << 24), (x - sCdf[lo]) & 0xfffu);
+    }
   }
 
   const uint32_t block = tile * kDecBlocksPerTile + hw;
@@ -362,7 +340,7 @@ __global__ __launch_bounds__(kDecThreads) void k_ans_decode(DecodeArgs a) {
     start = bw.y;
   }
   const uint8_t* gwords = ans + ansOverhead(nb) + 2u * (size_t)start;
-  __syncthreads();  // LUT visible to every wave (each half-wave's ring is private to its wave)
+  __syncthreads();  // LUT visible to every wave, scratch free (each half-wave's ring is private to its wave)
 
   RowSink<FT> sink;
   sink.init(a.out.ptr(b), archive, floatSize, (size_t)block * kBlockSize, hl);

@@ -46,6 +46,10 @@
 #include "format.h"
 #include "kernels_stats.h"
 
+#ifndef DGPU_ENC_ASM_STEP
+#define DGPU_ENC_ASM_STEP 0
+#endif
+
 namespace dgpu {
 
 // Upper bound of u16 words one block can emit: per lane, 128 symbols of at
@@ -121,6 +125,7 @@ __device__ uint64_t* g_phaseBuf = nullptr;
 #endif
 
 typedef __attribute__((address_space(3))) uint16_t LdsU16e;
+typedef uint16_t u16x2e __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4e __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4e LdsU4e;
 
@@ -196,7 +201,11 @@ struct ChunkSource16 {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         t[j] = x[j] >> 7;                                         // comp in bytes 0 and 2
-        q[j] = bitSelect(0xfffefffeu, x[j] << 1, x[j] >> 15);     // non-comp in bytes 0 and 2 (v_bfi)
+        // each half rotated left by one = w * 2 + (w >> 15) on packed u16 (v_pk_lshrrev_b16 + v_pk_mad_u16)
+        // (the compiler expands the multiply into a shift and an add; the asm keeps it to two ops)
+        const u16x2e w = __builtin_bit_cast(u16x2e, x[j]);
+        const uint32_t signs = __builtin_bit_cast(uint32_t, (u16x2e)(w >> 15));
+        asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(q[j]) : "v"(x[j]), "s"(0x00020002u), "v"(signs));
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -337,16 +346,43 @@ __device__ __forceinline__ uint32_t encodeRows(
     }
     state = write ? (state >> kEncodedBits) : state;
     // state = ((state / pdf) << P) + state % pdf + cdf
-    //       = state + cdf + (state / pdf) * (2^P - pdf)
-    const uint32_t t = __umulhi(state, e.y);
-    const uint32_t div = (t + state) >> (e.w >> 24);
+    //       = state + cdf + (state / pdf) * (2^P - pdf)      (table: k_normalize)
+    const uint32_t div = __umulhi(state, e.y) >> (e.w >> 24);
     const uint32_t next = __umul24(div, e.w) + state + e.z;
     state = valid ? next : state;
     outOff += __popc(vh);
   };
 
   // Full-block step: straight-line code, no exec-mask change and no branch.
-  auto stepFull = [&](const uint4 e) {
+  // The front half is hand-scheduled: the compiler does not form the SDWA select
+  // (renormalised state = state.WORD_1 where the lane emits) and would need an
+  // s_nop between the compare and the use of vcc as shift data.
+  //   write = state >= e.x;  vh = this half's 32 ballot bits
+  //   sel   = write ? state >> 16 : state;  t = umulhi(sel, e.y)
+  //   addr  = write ? stageBase + 2 * (outOff + popc(vh & lanesBelow)) : dummyAddr
+  const uint32_t halfShift = upper ? 32u : 0u;
+  auto stepFullAsm = [&](const uint4 e) {
+    uint32_t sel, t, addr;
+    uint64_t vh64;
+    asm("v_cmp_ge_u32 vcc, %[st], %[ex]\n\t"
+        "v_cndmask_b32_sdwa %[sel], %[st], %[st], vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+        "v_mul_hi_u32 %[t], %[sel], %[ey]\n\t"
+        "v_lshrrev_b64 v[78:79], %[hs], vcc\n\t"
+        "v_and_b32 %[addr], v78, %[lt]\n\t"
+        "v_bcnt_u32_b32 %[addr], %[addr], %[off]\n\t"
+        "v_lshl_add_u32 %[addr], %[addr], 1, %[sb]\n\t"
+        "v_cndmask_b32 %[addr], %[dm], %[addr], vcc"
+        : [sel] "=&v"(sel), [t] "=&v"(t), "=&{v[78:79]}"(vh64), [addr] "=&v"(addr)
+        : [st] "v"(state), [ex] "v"(e.x), [ey] "v"(e.y), [hs] "v"(halfShift), [lt] "v"(laneMaskLt),
+          [off] "v"(outOff), [sb] "v"(stageBase), [dm] "v"(dummyAddr)
+        : "vcc");
+    *(LdsU16e*)(uintptr_t)addr = (uint16_t)state;
+    const uint32_t div = t >> (e.w >> 24);
+    state = __umul24(div, e.w) + sel + e.z;
+    outOff += __popc((uint32_t)vh64);
+  };
+
+  auto stepFullC = [&](const uint4 e) {
     const bool write = state >= e.x;
     const uint64_t vote = __ballot(write);
     const uint32_t vh = upper ? (uint32_t)(vote >> 32) : (uint32_t)vote;
@@ -354,12 +390,10 @@ __device__ __forceinline__ uint32_t encodeRows(
     const uint32_t addr = write ? stageBase + 2u * idx : dummyAddr;
     *(LdsU16e*)(uintptr_t)addr = (uint16_t)state;
     state = write ? (state >> kEncodedBits) : state;
-    const uint32_t t = __umulhi(state, e.y);
-    const uint32_t div = (t + state) >> (e.w >> 24);
+    const uint32_t div = __umulhi(state, e.y) >> (e.w >> 24);
     state = __umul24(div, e.w) + state + e.z;
     outOff += __popc(vh);
   };
-
   if (kFull) {
     // 8 chunks of 16 rows; chunk c+1 is in flight in registers while chunk c is
     // consumed from the LDS ring (same wave writes and reads it: LDS ops of one
@@ -386,7 +420,11 @@ __device__ __forceinline__ uint32_t encodeRows(
         if (r % kFlushRows == 0) makeRoom();
         const uint4 cur_e = e[r % kAhead];
         if (r + kAhead < 16) e[r % kAhead] = ldsTableEntry(toff[r + kAhead]);
-        stepFull(cur_e);
+#if DGPU_ENC_ASM_STEP
+        stepFullAsm(cur_e);
+#else
+        stepFullC(cur_e);
+#endif
       }
     }
   } else {

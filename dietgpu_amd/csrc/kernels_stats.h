@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void k_normalize(NormalizeArgs a) {
   uint8_t* ans = nullptr;
   if (a.writeHeader) ans = a.out.ptr(b) + ansOffsetInArchive(a.floatType, total);
 
-  uint32_t pdf = 0, cdf = 0, magic = 0, shift = 0;
+  uint32_t pdf = 0, cdf = 0;
 
   if (a.tileDesc) {
     for (uint32_t i = tid; i < a.maxTiles; i += 256u) a.tileDesc[(size_t)b * a.maxTiles + i] = 0;
@@ -235,8 +235,19 @@ __global__ __launch_bounds__(256) void k_normalize(NormalizeArgs a) {
   }
 
   if (total != 0) {
+    // sum of the per-workgroup partial histograms, 8 loads in flight
     uint32_t count = 0;
-    for (uint32_t x = 0; x < a.histParts; ++x) count += a.hist[((size_t)b * a.histParts + x) * kNumSymbols + tid];
+    {
+      const uint32_t* hp = a.hist + (size_t)b * a.histParts * kNumSymbols + tid;
+      uint32_t x = 0;
+      for (; x + 8u <= a.histParts; x += 8u) {
+        uint32_t c[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c[k] = hp[(size_t)(x + k) * kNumSymbols];
+        count += ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
+      }
+      for (; x < a.histParts; ++x) count += hp[(size_t)x * kNumSymbols];
+    }
     // :215  qProb = kProbWeight * ((float)count / (float)totalNum), truncated.
     // Explicit round-to-nearest divide and multiply: no fma contraction, no
     // approximate reciprocal.
@@ -298,23 +309,52 @@ __global__ __launch_bounds__(256) void k_normalize(NormalizeArgs a) {
     for (uint32_t w = 0; w < wave; ++w) waveBase += sWave[w];
     cdf = waveBase + incl - pdf;
 
-    if (pdf > 0) {  // :349-358; undefined upstream for pdf == 0, never looked up
+  }
+
+  if (a.encTable) {
+    // Encoder entry.  The encoder needs q = floor(x / pdf) for states x < 2^31
+    // (x >= 16 always): q = umulhi(x, m) >> sh with a 32-bit m, no add-back step
+    // (the 33-bit "round-up" magic of the reference, :349-358, is only needed
+    // for full 32-bit dividends):
+    //   pdf = 2^k, k >= 1: m = 2^(32-k), sh = 0                 (exact shift)
+    //   otherwise, L = ceil(log2 pdf): m = floor(2^(31+L) / pdf) + 1, sh = L - 1
+    //     (m < 2^32 because pdf > 2^(L-1); error term x * e / (pdf * 2^(31+L)) with
+    //      e <= pdf < 2^L and x < 2^31 stays below 1 / pdf: the floor is exact)
+    //   pdf = 1: m = 2^32 - 1 gives q = x - 1; the missing (2^P - 1) is added to
+    //     the entry's cdf term instead
+    // state' = x + cdf + q * (2^P - pdf).  The double division is exact enough:
+    // the quotient is at least 2^-11 away from an integer, its error is < 2^-20.
+    uint32_t m = 0, sh = 0, cdfTerm = cdf;
+    if (pdf == 1u) {
+      m = 0xffffffffu;
+      cdfTerm = cdf + (W - 1u);
+    } else if (pdf > 1u) {
+      const uint32_t L = 32u - (uint32_t)__clz((int)(pdf - 1u));  // ceil(log2 pdf)
+      if ((pdf & (pdf - 1u)) == 0u) {
+        m = 1u << (32u - L);
+      } else {
+        sh = L - 1u;
+        m = (uint32_t)(unsigned long long)floor(ldexp(1.0, 31 + (int)L) / (double)pdf) + 1u;
+      }
+    }
+    uint4 e;
+    e.x = pdf << (kStateBits - P);
+    e.y = m;
+    e.z = cdfTerm;
+    e.w = ((W - pdf) & 0xffffffu) | (sh << 24);
+    a.encTable[b * kNumSymbols + tid] = e;
+  }
+  if (a.refTable) {
+    // the reference's table (pdf, cdf, 33-bit magic, shift), :349-358
+    uint32_t magic = 0, shift = 0;
+    if (pdf > 0) {  // undefined upstream for pdf == 0, never looked up
       shift = 32u - (uint32_t)__clz((int)(pdf - 1u));  // __clz(0) == 32
       const uint64_t one = 1;
       uint64_t magic64 = ((one << 32) * ((one << shift) - (uint64_t)pdf)) / (uint64_t)pdf + 1;
       magic = (uint32_t)magic64;
     }
+    a.refTable[b * kNumSymbols + tid] = make_uint4(pdf, cdf, magic, shift);
   }
-
-  if (a.encTable) {
-    uint4 e;
-    e.x = pdf << (kStateBits - P);
-    e.y = magic;
-    e.z = cdf;
-    e.w = ((W - pdf) & 0xffffffu) | (shift << 24);
-    a.encTable[b * kNumSymbols + tid] = e;
-  }
-  if (a.refTable) a.refTable[b * kNumSymbols + tid] = make_uint4(pdf, cdf, magic, shift);
 
   if (ans) {
     ((uint16_t*)(ans + sizeof(AnsHeader)))[tid] = (uint16_t)pdf;
