@@ -174,6 +174,18 @@ def algorithmic_bytes(kernel, codec, comp_total):
     }.get(kernel)
 
 
+def measured_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (cannot be collected inside this
+    process: rocprofv3 wraps the command).  None when no pass exists for this workload."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)["workloads"][workload][kernel]
+        return rec.get("hbm_bytes_per_launch")
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(kind, prob_bits, budget_s=12.0):
     """Times the CPU oracle (restatement of the reference algorithm; the reference
     itself has no CPU path) on this host, all cores, on a bounded sample."""
@@ -317,8 +329,11 @@ def main():
             ach = kernels[dom]["algorithmic_GBps"]
             roofline = {
                 "bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": measured_traffic(args.workload, dom),
                 "avg_us": kernels[dom]["avg_us"],
+                "algorithmic_bytes": algorithmic_bytes(dom, codec, comp_total),
+                "traffic_source": "profiles/r01_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                  "(tools/gpu_pmc.sh), (2*FETCH_SIZE + WRITE_SIZE) KiB per launch",
             }
         # whole-step figure: algorithmic bytes of encode + decode over the step time
         E = codec.B * codec.elems

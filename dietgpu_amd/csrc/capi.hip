@@ -445,7 +445,10 @@ uint32_t numComputeUnits() {
 // The encoder runs as persistent workgroups: as many as fit on the chip at once
 // (or fewer, if there are fewer tiles).  Float inputs use the small-stage /
 // spilling variant (6 workgroups per CU), raw bytes the worst-case stage.
-constexpr bool encodeSpills(uint32_t ft) { return ft != 0; }
+#ifndef DGPU_RAW_SPILLS
+#define DGPU_RAW_SPILLS 0
+#endif
+constexpr bool encodeSpills(uint32_t ft) { return ft != 0 || DGPU_RAW_SPILLS; }
 
 template <int P, uint32_t FT>
 uint32_t encodeGridPF(uint32_t tickets) {
