@@ -370,6 +370,20 @@ BatchView viewPointers(const uint64_t* ptrs_dev, const uint32_t* sizes_dev, uint
   return v;
 }
 
+// Workgroups per element of the internal histogram pass.  The hand-off to the
+// normalisation costs a few microseconds per workgroup (write-through + arrival
+// atomic), so workgroups should be long; two per CU already saturate HBM.  With
+// a large batch that is a few long workgroups per element, with a single large
+// tensor up to 256 of them.
+#ifndef DGPU_HIST_TARGET_WGS
+#define DGPU_HIST_TARGET_WGS 512
+#endif
+uint32_t histPartsFor(uint32_t B, uint32_t maxBytes) {
+  const uint32_t bySize = divUp(std::max(maxBytes, 1u), 32u * 1024u);
+  const uint32_t byBatch = divUp((uint32_t)DGPU_HIST_TARGET_WGS, std::max(B, 1u));
+  return std::max(1u, std::min(std::min(bySize, byBatch), 256u));
+}
+
 uint32_t gridX(uint32_t maxBytes, uint32_t bytesPerBlock, uint32_t cap) {
   uint32_t x = divUp(std::max(maxBytes, 1u), bytesPerBlock);
   return std::max(1u, std::min(x, cap));
@@ -514,12 +528,35 @@ int launchEncode(int P, uint32_t ft, const EncodeArgs& a, uint32_t grid, hipStre
 
 uint32_t tilesFor(uint32_t maxSize) { return divUp(divUp(maxSize, kBlockSize), kBlocksPerTile); }
 
-// Shared tail of every encode entry point: [checksum] -> histogram ->
-// normalise -> encode.  `in` holds raw bytes (floatType == 0: the ANS archive is
-// the whole output) or float words (floatType != 0: the encoder splits them on
-// the fly, the archive is a float archive).  No memset is needed on the common
-// path: histogram workgroups store partial histograms that k_normalize sums, and
-// k_normalize clears the tile descriptors + ticket for the encode kernel.
+// Library-owned arrival counters for the histogram -> normalisation hand-off
+// (HistFuse): 65536 u32 per (device, stream), zero at rest -- the kernel that uses
+// them puts them back to zero.  Keyed by stream because calls on one stream are
+// ordered while calls on different streams may overlap.
+int arrivalCounters(hipStream_t stream, uint32_t** out) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, uint32_t*> counters;
+  std::lock_guard<std::mutex> g(mu);
+  int dev = 0;
+  DGPU_HIP(hipGetDevice(&dev));
+  auto key = std::make_pair(dev, stream);
+  auto it = counters.find(key);
+  if (it == counters.end()) {
+    uint32_t* p = nullptr;
+    DGPU_HIP(hipMalloc((void**)&p, 65536 * sizeof(uint32_t)));
+    DGPU_HIP(hipMemset(p, 0, 65536 * sizeof(uint32_t)));  // once per (device, stream); synchronous
+    it = counters.emplace(key, p).first;
+  }
+  *out = it->second;
+  return DGPU_OK;
+}
+
+// Shared tail of every encode entry point: [checksum] -> histogram (+ fused
+// normalisation) -> encode.  `in` holds raw bytes (floatType == 0: the ANS
+// archive is the whole output) or float words (floatType != 0: the encoder
+// splits them on the fly, the archive is a float archive).  No memset is needed
+// on the common path: histogram workgroups store partial histograms, the last
+// one of each element sums and normalises them and clears the tile descriptors +
+// ticket for the encode kernel.
 int encodeCommon(
     TempArena& arena, hipStream_t stream, int P, bool useChecksum, uint32_t B,
     const BatchView& in, const BatchView& archives, uint32_t floatType, uint32_t maxSize,
@@ -539,51 +576,55 @@ int encodeCommon(
     DGPU_HIP(hipGetLastError());
   }
 
-  uint32_t histParts = 1;
-  if (!hist_dev) {
-    dim3 grid(gridX(maxSize * wordBytes, 32 * 1024, 64), B);
-    histParts = grid.x;
-    DGPU_ALLOC(histTemp, uint32_t, arena, (size_t)B * histParts * kNumSymbols);
-    switch (floatType) {
-      case 0:
-        DGPU_LAUNCH("k_histogram", stream, k_histogram, grid, dim3(256), 0, stream, in, histTemp, 1u);
-        break;
-      case kFloat16:
-        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kFloat16>), grid, dim3(256), 0, stream, in, histTemp, 1u);
-        break;
-      case kBFloat16:
-        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kBFloat16>), grid, dim3(256), 0, stream, in, histTemp, 1u);
-        break;
-      default:
-        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kFloat32>), grid, dim3(256), 0, stream, in, histTemp, 1u);
-        break;
-    }
-    DGPU_HIP(hipGetLastError());
-    hist_dev = histTemp;
-  }
-
   DGPU_ALLOC(table, uint4, arena, (size_t)B * kNumSymbols);
   DGPU_ALLOC(tileDesc, uint64_t, arena, (size_t)B * std::max(maxTiles, 1u) + 1);
   uint32_t* ticket = (uint32_t*)(tileDesc + (size_t)B * std::max(maxTiles, 1u));
-  {
-    NormalizeArgs n;
-    n.sizes = in;
-    n.hist = hist_dev;
-    n.histParts = histParts;
-    n.probBits = P;
-    n.encTable = table;
-    n.refTable = nullptr;
-    n.out = archives;
-    n.writeHeader = 1;
-    n.floatType = floatType;
-    // ANS-level checksums are not used in float mode (GpuFloatCodec.h:50)
-    n.useChecksum = (useChecksum && !floatType) ? 1 : 0;
-    n.checksum = (useChecksum && !floatType) ? checksumTemp : nullptr;
-    n.outSize = outSize_dev;
-    n.floatUseChecksum = (useChecksum && floatType) ? 1 : 0;
-    n.tileDesc = tileDesc;
-    n.maxTiles = maxTiles;
-    n.ticket = ticket;
+
+  NormalizeArgs n;
+  n.sizes = in;
+  n.hist = hist_dev;
+  n.histParts = 1;
+  n.probBits = P;
+  n.encTable = table;
+  n.refTable = nullptr;
+  n.out = archives;
+  n.writeHeader = 1;
+  n.floatType = floatType;
+  // ANS-level checksums are not used in float mode (GpuFloatCodec.h:50)
+  n.useChecksum = (useChecksum && !floatType) ? 1 : 0;
+  n.checksum = (useChecksum && !floatType) ? checksumTemp : nullptr;
+  n.outSize = outSize_dev;
+  n.floatUseChecksum = (useChecksum && floatType) ? 1 : 0;
+  n.tileDesc = tileDesc;
+  n.maxTiles = maxTiles;
+  n.ticket = ticket;
+
+  if (!hist_dev) {
+    dim3 grid(histPartsFor(B, maxSize * wordBytes), B);
+    DGPU_ALLOC(histTemp, uint32_t, arena, (size_t)B * grid.x * kNumSymbols);
+    HistFuse fuse;
+    int rc = arrivalCounters(stream, &fuse.arrive);
+    if (rc) return rc;
+    n.hist = histTemp;
+    n.histParts = grid.x;
+    fuse.norm = n;
+    switch (floatType) {
+      case 0:
+        DGPU_LAUNCH("k_histogram", stream, k_histogram, grid, dim3(256), 0, stream, in, histTemp, 1u, fuse);
+        break;
+      case kFloat16:
+        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kFloat16>), grid, dim3(256), 0, stream, in, histTemp, 1u, fuse);
+        break;
+      case kBFloat16:
+        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kBFloat16>), grid, dim3(256), 0, stream, in, histTemp, 1u, fuse);
+        break;
+      default:
+        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kFloat32>), grid, dim3(256), 0, stream, in, histTemp, 1u, fuse);
+        break;
+    }
+    DGPU_HIP(hipGetLastError());
+  } else {
+    // caller-supplied histogram: stand-alone normalisation
     DGPU_LAUNCH("k_normalize", stream, k_normalize, dim3(B), dim3(256), 0, stream, n);
     DGPU_HIP(hipGetLastError());
   }
@@ -870,7 +911,7 @@ uint32_t dgpu_float_max_compressed_size(uint32_t ft, uint32_t n) {
 
 static size_t encodeTempBytes(uint32_t B, uint32_t maxBytes, uint32_t wordBytes, bool spills) {
   size_t tiles = std::max(tilesFor(maxBytes), 1u);
-  size_t parts = gridX(maxBytes * wordBytes, 32 * 1024, 64);
+  size_t parts = histPartsFor(B, maxBytes * wordBytes);
   size_t t = 0;
   t += alignUp((size_t)B * 4, kTempAlign);                                        // checksums
   t += alignUp((size_t)B * parts * kNumSymbols * 4, kTempAlign);                  // partial histograms
@@ -1179,7 +1220,10 @@ int dgpu_ans_histogram_batch_stride(
   DGPU_HIP(hipMemsetAsync(histogram_dev, 0, (size_t)numInBatch * kNumSymbols * 4, (hipStream_t)stream));
   BatchView in = viewStride(in_dev, inPerBatchStride, inPerBatchSize);
   dim3 grid(gridX(inPerBatchSize, 32 * 1024, 64), numInBatch);
-  hipLaunchKernelGGL(k_histogram, grid, dim3(256), 0, (hipStream_t)stream, in, histogram_dev, 0u);
+  HistFuse noFuse;
+  noFuse.arrive = nullptr;
+  noFuse.norm = NormalizeArgs{};
+  hipLaunchKernelGGL(k_histogram, grid, dim3(256), 0, (hipStream_t)stream, in, histogram_dev, 0u, noFuse);
   DGPU_HIP(hipGetLastError());
   return DGPU_OK;
 }

@@ -656,7 +656,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 // GpuFloatCompress.cuh:144, 352-364).  grid = (xBlocks, B), 256 threads;
 // hist must be zeroed first.
 template <uint32_t FT>
-__global__ __launch_bounds__(256) void k_float_histogram(BatchView in, uint32_t* __restrict__ hist, uint32_t partial) {
+__global__ __launch_bounds__(256) void k_float_histogram(BatchView in, uint32_t* __restrict__ hist, uint32_t partial, HistFuse fuse) {
   __shared__ uint32_t bins[kHistBlockWords];
   const uint32_t tid = threadIdx.x;
   const uint32_t b = blockIdx.y;
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256) void k_float_histogram(BatchView in, uint32_t*
     histAdd(myBins, c);
   }
   __syncthreads();
-  histStore(hist, partial, b, tid, histFold(bins, tid));
+  histStore(hist, partial, fuse, b, tid, histFold(bins, tid));
 }
 
 }  // namespace dgpu

@@ -32,149 +32,6 @@ __device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v, uint32_t lane)
 }
 
 // ---------------------------------------------------------------------------
-// Histogram bins in LDS.  Entropy-coder inputs are skewed (one exponent value
-// can be a third of the data) and ds_add_u32 serialises lanes of one
-// instruction that hit the same address or bank, which made a per-wave
-// privatised layout run at ~2 lane-updates per clock per CU.  Layout used
-// instead: bin-major with kHistSlots lane slots per bin,
-//     word(bin, lane) = bin * 16 + (lane & 15),  bank = 16 * (bin & 1) + (lane & 15)
-// so lanes with different slots can never collide and the two lanes that share
-// a slot within a 32-lane LDS pass (l and l + 16) collide at most 2-way.  The
-// four wavefronts of a workgroup share the same 16 KiB (ds_add is atomic;
-// different waves are different instructions and merely interleave).
-constexpr uint32_t kHistSlots = 16;
-constexpr uint32_t kHistBlockWords = kNumSymbols * kHistSlots;  // 16 KiB
-
-__device__ __forceinline__ void histZero(uint32_t* bins, uint32_t tid) {
-  for (uint32_t i = tid; i < kHistBlockWords / 4u; i += 256u) ((uint4*)bins)[i] = make_uint4(0, 0, 0, 0);
-}
-// this lane's slot column; bin c lives at mine[c * kHistSlots]
-__device__ __forceinline__ uint32_t* histMine(uint32_t* bins, uint32_t tid) {
-  return bins + (tid & (kHistSlots - 1u));
-}
-__device__ __forceinline__ void histAdd(uint32_t* mine, uint32_t c) { atomicAdd(&mine[c * kHistSlots], 1u); }
-// total of bin `tid` over all slots
-__device__ __forceinline__ uint32_t histFold(const uint32_t* bins, uint32_t tid) {
-  const uint4* p = (const uint4*)(bins + tid * kHistSlots);
-  uint32_t sum = 0;
-#pragma unroll
-  for (uint32_t k = 0; k < kHistSlots / 4u; ++k) {
-    const uint4 v = p[k];
-    sum += v.x + v.y + v.z + v.w;
-  }
-  return sum;
-}
-
-// Histogram kernel: 16-byte loads with a byte-wise head/tail so any start
-// alignment works (the reference test uses stride size+11,
-// ANSStatisticsTest.cu:52-57).  grid = (xBlocks, B), 256 threads.
-__device__ __forceinline__ void histAdd4(uint32_t* mine, uint32_t x) {
-  histAdd(mine, x & 0xff);
-  histAdd(mine, (x >> 8) & 0xff);
-  histAdd(mine, (x >> 16) & 0xff);
-  histAdd(mine, x >> 24);
-}
-
-// `partial` != 0: this workgroup stores its 256 totals to hist[(b * gridDim.x + blockIdx.x) * 256 + bin]
-// (no atomics, no zero-initialisation needed; k_normalize adds the parts up).  Otherwise it adds
-// them atomically into hist[b][256], which must have been zeroed.
-__device__ __forceinline__ void histStore(uint32_t* __restrict__ hist, uint32_t partial, uint32_t b, uint32_t tid, uint32_t sum) {
-  if (partial) {
-    hist[((size_t)b * gridDim.x + blockIdx.x) * kNumSymbols + tid] = sum;
-  } else if (sum) {
-    atomicAdd(&hist[b * kNumSymbols + tid], sum);
-  }
-}
-
-__global__ __launch_bounds__(256) void k_histogram(BatchView in, uint32_t* __restrict__ hist, uint32_t partial) {
-  __shared__ uint32_t bins[kHistBlockWords];
-  const uint32_t tid = threadIdx.x;
-  const uint32_t b = blockIdx.y;
-  histZero(bins, tid);
-  __syncthreads();
-
-  uint32_t* myBins = histMine(bins, tid);
-  const uint8_t* p = in.ptr(b);
-  const uint32_t size = in.size(b);
-
-  // bytes before the first 16-byte boundary
-  uint32_t head = (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u);
-  head = head < size ? head : size;
-  const uint32_t remaining = size - head;
-  const uint32_t numVec = remaining / 16u;
-  const uint4* pv = (const uint4*)(p + head);
-
-  if (blockIdx.x == 0 && tid < head) histAdd(myBins, p[tid]);
-
-  // four 16-byte loads in flight per lane (the kernel is HBM-latency bound otherwise)
-  const uint32_t stride = gridDim.x * 256u;
-  uint32_t i = blockIdx.x * 256u + tid;
-  for (; i + 3u * stride < numVec; i += 4u * stride) {
-    const uint4 v0 = streamLoad<DGPU_NT_HIST_LOADS != 0>(&pv[i]), v1 = streamLoad<DGPU_NT_HIST_LOADS != 0>(&pv[i + stride]), v2 = streamLoad<DGPU_NT_HIST_LOADS != 0>(&pv[i + 2u * stride]), v3 = streamLoad<DGPU_NT_HIST_LOADS != 0>(&pv[i + 3u * stride]);
-    histAdd4(myBins, v0.x); histAdd4(myBins, v0.y); histAdd4(myBins, v0.z); histAdd4(myBins, v0.w);
-    histAdd4(myBins, v1.x); histAdd4(myBins, v1.y); histAdd4(myBins, v1.z); histAdd4(myBins, v1.w);
-    histAdd4(myBins, v2.x); histAdd4(myBins, v2.y); histAdd4(myBins, v2.z); histAdd4(myBins, v2.w);
-    histAdd4(myBins, v3.x); histAdd4(myBins, v3.y); histAdd4(myBins, v3.z); histAdd4(myBins, v3.w);
-  }
-  for (; i < numVec; i += stride) {
-    const uint4 v = streamLoad<DGPU_NT_HIST_LOADS != 0>(&pv[i]);
-    histAdd4(myBins, v.x);
-    histAdd4(myBins, v.y);
-    histAdd4(myBins, v.z);
-    histAdd4(myBins, v.w);
-  }
-
-  if (blockIdx.x == 0) {
-    uint32_t t = numVec * 16u + tid;
-    if (t < remaining) histAdd(myBins, p[head + t]);
-  }
-  __syncthreads();
-
-  histStore(hist, partial, b, tid, histFold(bins, tid));
-}
-
-// ---------------------------------------------------------------------------
-// Checksum: XOR of all bytes, folded to 8 bits (GpuChecksum.cuh:26-93).
-// grid = (xBlocks, B), 256 threads; out[] must be zeroed first.
-// `floatWords` != 0 reproduces the float-path quirk: the provider's size is in
-// float words but is consumed as a byte count, so only the first `size` bytes
-// are covered (GpuFloatCompress.cuh:466-468).  `sizesOverride` (nullable) lets
-// the decode side checksum exactly the decoded size.
-__global__ __launch_bounds__(256) void k_checksum(
-    BatchView in, const uint32_t* __restrict__ sizesOverride, uint32_t* __restrict__ out) {
-  __shared__ uint32_t partial[4];
-  const uint32_t tid = threadIdx.x;
-  const uint32_t b = blockIdx.y;
-  const uint8_t* p = in.ptr(b);
-  uint32_t size = sizesOverride ? sizesOverride[b] : in.size(b);
-
-  uint32_t head = (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u);
-  head = head < size ? head : size;
-  const uint32_t remaining = size - head;
-  const uint32_t numVec = remaining / 16u;
-  const uint4* pv = (const uint4*)(p + head);
-
-  uint32_t c = 0;
-  if (blockIdx.x == 0 && tid < head) c ^= p[tid];
-  for (uint32_t i = blockIdx.x * 256u + tid; i < numVec; i += gridDim.x * 256u) {
-    uint4 v = pv[i];
-    c ^= v.x ^ v.y ^ v.z ^ v.w;
-  }
-  if (blockIdx.x == 0) {
-    uint32_t i = numVec * 16u + tid;
-    if (i < remaining) c ^= p[head + i];
-  }
-  c = (c ^ (c >> 8) ^ (c >> 16) ^ (c >> 24)) & 0xffu;
-  c = waveReduceXor(c);
-  if ((tid & 63u) == 0) partial[tid >> 6] = c;
-  __syncthreads();
-  if (tid == 0) {
-    c = partial[0] ^ partial[1] ^ partial[2] ^ partial[3];
-    if (c) atomicXor(&out[b], c);
-  }
-}
-
-// ---------------------------------------------------------------------------
 // Probability normalisation (GpuANSStatistics.cuh:178-367), one 256-thread
 // workgroup per batch element.  Produces
 //   encTable[b][sym] = {thresh = pdf << (31-P), magic, cdf, (2^P - pdf) | shift << 24}
@@ -210,7 +67,11 @@ struct NormalizeArgs {
   uint32_t* ticket;          // nullable
 };
 
-__global__ __launch_bounds__(256) void k_normalize(NormalizeArgs a) {
+// One 256-thread workgroup normalises batch element b.  kCoherent: the partial
+// histograms were written by other workgroups of the SAME kernel (write-through
+// agent-scope stores) and are read with agent-scope loads.
+template <bool kCoherent>
+__device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const uint32_t b) {
   __shared__ uint32_t sKeys[kNumSymbols];
   __shared__ uint32_t sSorted[kNumSymbols];
   __shared__ uint32_t sPdf[kNumSymbols];
@@ -219,7 +80,6 @@ __global__ __launch_bounds__(256) void k_normalize(NormalizeArgs a) {
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
   const uint32_t wave = tid >> 6;
-  const uint32_t b = blockIdx.x;
   const uint32_t total = a.sizes.size(b);
   const int P = a.probBits;
   const uint32_t W = 1u << P;
@@ -235,18 +95,29 @@ __global__ __launch_bounds__(256) void k_normalize(NormalizeArgs a) {
   }
 
   if (total != 0) {
-    // sum of the per-workgroup partial histograms, 8 loads in flight
+    // sum of the per-workgroup partial histograms, up to 16 loads in flight
     uint32_t count = 0;
     {
       const uint32_t* hp = a.hist + (size_t)b * a.histParts * kNumSymbols + tid;
+      auto part = [&](uint32_t x) -> uint32_t {
+        const uint32_t* q = hp + (size_t)x * kNumSymbols;
+        return kCoherent ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+      };
       uint32_t x = 0;
-      for (; x + 8u <= a.histParts; x += 8u) {
-        uint32_t c[8];
+      for (; x + 16u <= a.histParts; x += 16u) {
+        uint32_t c[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) c[k] = hp[(size_t)(x + k) * kNumSymbols];
-        count += ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
+        for (int k = 0; k < 16; ++k) c[k] = part(x + k);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) count += c[k];
       }
-      for (; x < a.histParts; ++x) count += hp[(size_t)x * kNumSymbols];
+      for (; x + 4u <= a.histParts; x += 4u) {
+        uint32_t c[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c[k] = part(x + k);
+        count += (c[0] + c[1]) + (c[2] + c[3]);
+      }
+      for (; x < a.histParts; ++x) count += part(x);
     }
     // :215  qProb = kProbWeight * ((float)count / (float)totalNum), truncated.
     // Explicit round-to-nearest divide and multiply: no fma contraction, no
@@ -383,6 +254,184 @@ __global__ __launch_bounds__(256) void k_normalize(NormalizeArgs a) {
         }
       }
     }
+  }
+}
+
+// Stand-alone normalisation (caller-supplied histograms, dgpu_ans_calc_weights).  grid = B.
+__global__ __launch_bounds__(256) void k_normalize(NormalizeArgs a) { normalizeElement<false>(a, blockIdx.x); }
+
+// ---------------------------------------------------------------------------
+// Histogram -> normalisation hand-off inside one kernel.  Every histogram
+// workgroup of element b publishes its partial counts (write-through stores),
+// waits for them to be performed, and bumps arrive[b]; the workgroup that
+// observes the last arrival normalises the element on the spot, so the table is
+// being built for early elements while late ones are still being counted, and
+// there is no separate kernel (launch gap + ramp + 256 mostly idle CUs) on the
+// critical path.  arrive[] is library-owned, zero at rest: the normalising
+// workgroup resets it.  arrive == nullptr: plain histogram.
+struct HistFuse {
+  uint32_t* arrive;  // [B], zero at launch
+  NormalizeArgs norm;
+};
+
+// ---------------------------------------------------------------------------
+// Histogram bins in LDS.  Entropy-coder inputs are skewed (one exponent value
+// can be a third of the data) and ds_add_u32 serialises lanes of one
+// instruction that hit the same address or bank, which made a per-wave
+// privatised layout run at ~2 lane-updates per clock per CU.  Layout used
+// instead: bin-major with kHistSlots lane slots per bin,
+//     word(bin, lane) = bin * 16 + (lane & 15),  bank = 16 * (bin & 1) + (lane & 15)
+// so lanes with different slots can never collide and the two lanes that share
+// a slot within a 32-lane LDS pass (l and l + 16) collide at most 2-way.  The
+// four wavefronts of a workgroup share the same 16 KiB (ds_add is atomic;
+// different waves are different instructions and merely interleave).
+constexpr uint32_t kHistSlots = 16;
+constexpr uint32_t kHistBlockWords = kNumSymbols * kHistSlots;  // 16 KiB
+
+__device__ __forceinline__ void histZero(uint32_t* bins, uint32_t tid) {
+  for (uint32_t i = tid; i < kHistBlockWords / 4u; i += 256u) ((uint4*)bins)[i] = make_uint4(0, 0, 0, 0);
+}
+// this lane's slot column; bin c lives at mine[c * kHistSlots]
+__device__ __forceinline__ uint32_t* histMine(uint32_t* bins, uint32_t tid) {
+  return bins + (tid & (kHistSlots - 1u));
+}
+__device__ __forceinline__ void histAdd(uint32_t* mine, uint32_t c) { atomicAdd(&mine[c * kHistSlots], 1u); }
+// total of bin `tid` over all slots
+__device__ __forceinline__ uint32_t histFold(const uint32_t* bins, uint32_t tid) {
+  const uint4* p = (const uint4*)(bins + tid * kHistSlots);
+  uint32_t sum = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kHistSlots / 4u; ++k) {
+    const uint4 v = p[k];
+    sum += v.x + v.y + v.z + v.w;
+  }
+  return sum;
+}
+
+// Histogram kernel: 16-byte loads with a byte-wise head/tail so any start
+// alignment works (the reference test uses stride size+11,
+// ANSStatisticsTest.cu:52-57).  grid = (xBlocks, B), 256 threads.
+__device__ __forceinline__ void histAdd4(uint32_t* mine, uint32_t x) {
+  histAdd(mine, x & 0xff);
+  histAdd(mine, (x >> 8) & 0xff);
+  histAdd(mine, (x >> 16) & 0xff);
+  histAdd(mine, x >> 24);
+}
+
+// `partial` != 0: this workgroup stores its 256 totals to hist[(b * gridDim.x + blockIdx.x) * 256 + bin]
+// (no atomics, no zero-initialisation needed; the normalisation adds the parts up).  Otherwise it adds
+// them atomically into hist[b][256], which must have been zeroed.  With f.arrive set (partial mode
+// only) the last workgroup of the element to get here also normalises it.
+__device__ __forceinline__ void histStore(uint32_t* __restrict__ hist, uint32_t partial, const HistFuse& f, uint32_t b, uint32_t tid, uint32_t sum) {
+  if (!partial) {
+    if (sum) atomicAdd(&hist[b * kNumSymbols + tid], sum);
+    return;
+  }
+  uint32_t* slot = &hist[((size_t)b * gridDim.x + blockIdx.x) * kNumSymbols + tid];
+  if (!f.arrive) {
+    *slot = sum;
+    return;
+  }
+  __shared__ uint32_t sLast;
+  __hip_atomic_store(slot, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // ... and performed
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t prev = __hip_atomic_fetch_add(&f.arrive[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sLast = (prev + 1u == gridDim.x) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (sLast) {  // uniform
+    if (tid == 0) __hip_atomic_store(&f.arrive[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    normalizeElement<true>(f.norm, b);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_histogram(BatchView in, uint32_t* __restrict__ hist, uint32_t partial, HistFuse fuse) {
+  __shared__ uint32_t bins[kHistBlockWords];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t b = blockIdx.y;
+  histZero(bins, tid);
+  __syncthreads();
+
+  uint32_t* myBins = histMine(bins, tid);
+  const uint8_t* p = in.ptr(b);
+  const uint32_t size = in.size(b);
+
+  // bytes before the first 16-byte boundary
+  uint32_t head = (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u);
+  head = head < size ? head : size;
+  const uint32_t remaining = size - head;
+  const uint32_t numVec = remaining / 16u;
+  const uint4* pv = (const uint4*)(p + head);
+
+  if (blockIdx.x == 0 && tid < head) histAdd(myBins, p[tid]);
+
+  // four 16-byte loads in flight per lane (the kernel is HBM-latency bound otherwise)
+  const uint32_t stride = gridDim.x * 256u;
+  uint32_t i = blockIdx.x * 256u + tid;
+  for (; i + 3u * stride < numVec; i += 4u * stride) {
+    const uint4 v0 = streamLoad<DGPU_NT_HIST_LOADS != 0>(&pv[i]), v1 = streamLoad<DGPU_NT_HIST_LOADS != 0>(&pv[i + stride]), v2 = streamLoad<DGPU_NT_HIST_LOADS != 0>(&pv[i + 2u * stride]), v3 = streamLoad<DGPU_NT_HIST_LOADS != 0>(&pv[i + 3u * stride]);
+    histAdd4(myBins, v0.x); histAdd4(myBins, v0.y); histAdd4(myBins, v0.z); histAdd4(myBins, v0.w);
+    histAdd4(myBins, v1.x); histAdd4(myBins, v1.y); histAdd4(myBins, v1.z); histAdd4(myBins, v1.w);
+    histAdd4(myBins, v2.x); histAdd4(myBins, v2.y); histAdd4(myBins, v2.z); histAdd4(myBins, v2.w);
+    histAdd4(myBins, v3.x); histAdd4(myBins, v3.y); histAdd4(myBins, v3.z); histAdd4(myBins, v3.w);
+  }
+  for (; i < numVec; i += stride) {
+    const uint4 v = streamLoad<DGPU_NT_HIST_LOADS != 0>(&pv[i]);
+    histAdd4(myBins, v.x);
+    histAdd4(myBins, v.y);
+    histAdd4(myBins, v.z);
+    histAdd4(myBins, v.w);
+  }
+
+  if (blockIdx.x == 0) {
+    uint32_t t = numVec * 16u + tid;
+    if (t < remaining) histAdd(myBins, p[head + t]);
+  }
+  __syncthreads();
+
+  histStore(hist, partial, fuse, b, tid, histFold(bins, tid));
+}
+
+// ---------------------------------------------------------------------------
+// Checksum: XOR of all bytes, folded to 8 bits (GpuChecksum.cuh:26-93).
+// grid = (xBlocks, B), 256 threads; out[] must be zeroed first.
+// `floatWords` != 0 reproduces the float-path quirk: the provider's size is in
+// float words but is consumed as a byte count, so only the first `size` bytes
+// are covered (GpuFloatCompress.cuh:466-468).  `sizesOverride` (nullable) lets
+// the decode side checksum exactly the decoded size.
+__global__ __launch_bounds__(256) void k_checksum(
+    BatchView in, const uint32_t* __restrict__ sizesOverride, uint32_t* __restrict__ out) {
+  __shared__ uint32_t partial[4];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t b = blockIdx.y;
+  const uint8_t* p = in.ptr(b);
+  uint32_t size = sizesOverride ? sizesOverride[b] : in.size(b);
+
+  uint32_t head = (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u);
+  head = head < size ? head : size;
+  const uint32_t remaining = size - head;
+  const uint32_t numVec = remaining / 16u;
+  const uint4* pv = (const uint4*)(p + head);
+
+  uint32_t c = 0;
+  if (blockIdx.x == 0 && tid < head) c ^= p[tid];
+  for (uint32_t i = blockIdx.x * 256u + tid; i < numVec; i += gridDim.x * 256u) {
+    uint4 v = pv[i];
+    c ^= v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (blockIdx.x == 0) {
+    uint32_t i = numVec * 16u + tid;
+    if (i < remaining) c ^= p[head + i];
+  }
+  c = (c ^ (c >> 8) ^ (c >> 16) ^ (c >> 24)) & 0xffu;
+  c = waveReduceXor(c);
+  if ((tid & 63u) == 0) partial[tid >> 6] = c;
+  __syncthreads();
+  if (tid == 0) {
+    c = partial[0] ^ partial[1] ^ partial[2] ^ partial[3];
+    if (c) atomicXor(&out[b], c);
   }
 }
 
