@@ -577,8 +577,8 @@ int encodeCommon(
   }
 
   DGPU_ALLOC(table, uint4, arena, (size_t)B * kNumSymbols);
-  DGPU_ALLOC(tileDesc, uint64_t, arena, (size_t)B * std::max(maxTiles, 1u) + 1);
-  uint32_t* ticket = (uint32_t*)(tileDesc + (size_t)B * std::max(maxTiles, 1u));
+  DGPU_ALLOC(tileDesc, uint64_t, arena, (size_t)B * std::max(maxTiles, 1u));
+  DGPU_ALLOC(ticket, uint32_t, arena, 64 * kTicketStride);
 
   NormalizeArgs n;
   n.sizes = in;
@@ -916,7 +916,8 @@ static size_t encodeTempBytes(uint32_t B, uint32_t maxBytes, uint32_t wordBytes,
   t += alignUp((size_t)B * 4, kTempAlign);                                        // checksums
   t += alignUp((size_t)B * parts * kNumSymbols * 4, kTempAlign);                  // partial histograms
   t += alignUp((size_t)B * kNumSymbols * 16, kTempAlign);                         // encoder table
-  t += alignUp(((size_t)B * tiles + 1) * 8, kTempAlign);                          // tile descriptors + ticket
+  t += alignUp((size_t)B * tiles * 8, kTempAlign);                                // tile descriptors
+  t += alignUp((size_t)64 * kTicketStride * 4, kTempAlign);                       // ticket counters
   if (spills) {
     // spill slots of the persistent encoder workgroups (bounded by what fits on the chip)
     size_t perCu = (160u * 1024u) / encLdsBytes(9, true);

@@ -46,6 +46,9 @@
 #include "format.h"
 #include "kernels_stats.h"
 
+#ifndef DGPU_STATIC_SCHEDULE
+#define DGPU_STATIC_SCHEDULE 0
+#endif
 #ifndef DGPU_ENC_ASM_STEP
 #define DGPU_ENC_ASM_STEP 0
 #endif
@@ -97,12 +100,19 @@ struct EncodeArgs {
   uint32_t numInBatch;       // B
   uint32_t numTickets;       // B * maxTiles
   uint64_t* tileDesc;        // [B][maxTiles], zeroed before launch
-  uint32_t* ticket;          // zeroed before launch
+  uint32_t* ticket;          // kTicketCounters counters, kTicketStride words apart, zeroed before launch
   uint16_t* spill;           // [gridDim.x][kBlocksPerTile][encSpillSlotWords(P)] (kSpill kernels only)
   uint32_t* outSize;         // [B] nullable
   uint32_t useChecksum;      // float header only
   const uint32_t* checksum;  // [B] nullable (float header only)
 };
+
+// Ticket counters: up to kTicketCounters of them, 128 bytes apart.
+#ifndef DGPU_TICKET_COUNTERS
+#define DGPU_TICKET_COUNTERS 8
+#endif
+constexpr uint32_t kTicketCounters = DGPU_TICKET_COUNTERS;
+constexpr uint32_t kTicketStride = 32;    // u32 words between counters
 
 struct TileShared {
   uint32_t ticket;
@@ -128,6 +138,14 @@ typedef __attribute__((address_space(3))) uint16_t LdsU16e;
 typedef uint16_t u16x2e __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4e __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4e LdsU4e;
+
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() also
+// drains the vector-memory counter (s_waitcnt vmcnt(0)); inside the tile loop no
+// wave reads global memory another wave of its workgroup wrote, so the four
+// barriers of a tile need not wait for outstanding archive stores / prefetches.
+__device__ __forceinline__ void ldsBarrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 // table entry at an absolute LDS address
 __device__ __forceinline__ uint4 ldsTableEntry(uint32_t addr) {
@@ -472,13 +490,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   uint16_t* spillSlot = kSpill ? a.spill + ((size_t)blockIdx.x * kBlocksPerTile + hw) * encSpillSlotWords(P) : nullptr;
 
   // Persistent workgroup: tiles are drawn from the ticket counter until it runs out.
+#if DGPU_STATIC_SCHEDULE  // analysis only: UNSAFE unless every workgroup of the grid is resident
+  for (uint32_t ticket = blockIdx.x; ticket < a.numTickets; ticket += gridDim.x) {
+#else
+  // Several ticket counters instead of one (1536 workgroups queueing on a single
+  // address cost ~12 us at kernel start): with C counters, C the largest power
+  // of two <= kTicketCounters that divides B, counter x hands out the tickets
+  // x, x + C, x + 2C, ...  A ticket's predecessors t - B, t - 2B, ... are in its
+  // own residue class and smaller tickets of a class are always drawn first, so
+  // the no-deadlock argument is unchanged.  A workgroup starts at the counter
+  // matching the XCD it runs on (workgroups are dealt to XCDs round robin, so
+  // the counters drain evenly) and moves on when a counter is exhausted.
+  uint32_t numCounters = kTicketCounters;
+  while (a.numInBatch % numCounters) numCounters >>= 1;
+  uint32_t myCounter = 0;
+  if (tid == 0) myCounter = blockIdx.x % numCounters;
+  uint32_t exhausted = 0;  // thread 0: counters seen to be exhausted
   for (;;) {
     if (tid == 0) {
-      sh->ticket = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t t = 0xffffffffu;
+      while (exhausted < numCounters) {
+        const uint32_t k = __hip_atomic_fetch_add(a.ticket + myCounter * kTicketStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t cand = myCounter + k * numCounters;
+        if (cand < a.numTickets) {
+          t = cand;
+          break;
+        }
+        ++exhausted;  // every counter is visited at most once more after it ran dry
+        myCounter = (myCounter + 1u) % numCounters;
+      }
+      sh->ticket = t;
     }
-    __syncthreads();
+    ldsBarrier();
     const uint32_t ticket = sh->ticket;
     if (ticket >= a.numTickets) break;  // uniform for the workgroup
+#endif
 #ifdef DGPU_PHASE_TIMING
     const uint32_t phaseSlot = ticket;
 #endif
@@ -493,12 +539,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     const uint32_t nb = divUp(size, kBlockSize);
     const uint32_t numTiles = divUp(nb, kBlocksPerTile);
     if (tile >= numTiles) {  // uniform; nobody reads sh->ticket after the barrier below
-      __syncthreads();
+#if !DGPU_STATIC_SCHEDULE
+      ldsBarrier();
+#endif
       continue;
     }
 
     sTable[tid] = a.encTable[b * kNumSymbols + tid];
-    __syncthreads();
+    ldsBarrier();
     DGPU_PHASE(1);
 
     const uint8_t* in = a.in.ptr(b);
@@ -569,7 +617,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       if (words + hl < padded) stage[words + hl] = 0;
     }
     if (hl == 0) sh->words[hw] = haveBlock ? spilled + words : 0u;
-    __syncthreads();
+    ldsBarrier();
     DGPU_PHASE(3);
 
     if (wave == 0) {
@@ -630,13 +678,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         blockWords[nb] = make_uint2(0u, 0u);  // alignment pad entry
       }
     }
-    __syncthreads();
+    ldsBarrier();
     DGPU_PHASE(4);
 
     if (haveBlock) {
       uint4* dst = (uint4*)(ans + ansOverhead(nb) + 2u * (size_t)(sh->tileBase + sh->localOff[hw]));
       if (kSpill && spilled) {
-        // spilled vectors first (written by this wave before the barriers above)
+        // spilled vectors first (written by this wave; its stores must have been performed)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint4* sp = (const uint4*)spillSlot;
         const uint32_t sv = spilled / kBlockAlignWords;
         for (uint32_t i = hl; i < sv; i += 32u) streamStore<DGPU_NT_ENC_STORES != 0>(&dst[i], sp[i]);

@@ -91,7 +91,7 @@ __device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const u
 
   if (a.tileDesc) {
     for (uint32_t i = tid; i < a.maxTiles; i += 256u) a.tileDesc[(size_t)b * a.maxTiles + i] = 0;
-    if (b == 0 && tid == 0) *a.ticket = 0;
+    if (b == 0 && tid < 64u) a.ticket[tid * 32u] = 0;  // the encoder's ticket counters (<= 64, 32 words apart)
   }
 
   if (total != 0) {

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 DBG = "/tmp/libdietgpu_amd_dbg.so"
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                       "-DDGPU_PHASE_TIMING", "-o", DBG, os.path.join(ROOT, "dietgpu_amd/csrc/capi.hip")])
+                       "-DDGPU_PHASE_TIMING"] + os.environ.get("DGPU_EXTRA_FLAGS", "").split() + ["-o", DBG, os.path.join(ROOT, "dietgpu_amd/csrc/capi.hip")])
 import dietgpu_amd.build as b
 b.LIB_PATH = DBG
 import dietgpu_amd._lib as L
@@ -38,7 +38,12 @@ assert lib.dgpu_debug_set_phase_buffer(C.c_void_p(buf.data_ptr())) == 0
 codec.encode()
 torch.cuda.synchronize()
 t = buf.cpu().numpy()
-t = t[t[:, 0] != 0]
+slot = np.arange(t.shape[0])
+keep = t[:, 0] != 0
+elem = (slot % 256)[keep]
+t = t[keep]
+print("tiles whose element b has b % 8 == XCD of the workgroup (blockIdx % 8):",
+      int(((elem % 8) == (t[:, 7] % 8)).sum()), "of", t.shape[0])
 names = ["ticket->table", "rows", "states+sync", "lookback", "copy"]
 print(f"{wl}: {t.shape[0]} tiles")
 for k, n in enumerate(names):
@@ -46,8 +51,16 @@ for k, n in enumerate(names):
     print(f"  {n:16s} mean {d.mean():9.0f}  p50 {np.median(d):9.0f}  p95 {np.percentile(d, 95):9.0f} cycles (s_memtime @100MHz? ticks)")
 tot = (t[:, 5] - t[:, 0]).astype(np.float64)
 print(f"  {'total':16s} mean {tot.mean():9.0f}")
-span = int(t[:, 5].max() - t[:, 0].min())
-print("  span of kernel (max end - min start):", span)
+# the cycle counters of different XCDs are not aligned: spans are per XCD
+xcd = t[:, 7] % 8
+spans = [int(t[xcd == x][:, 5].max() - t[xcd == x][:, 0].min()) for x in range(8) if (xcd == x).any()]
+print("  span per XCD (max end - min start):", spans)
+for x in range(8):
+    r = t[xcd == x]
+    if len(r):
+        t0x = r[:, 0].min()
+        starts = np.sort(r[:, 0] - t0x)
+        print(f"    xcd {x}: tiles {len(r)}  tile starts p10/p50/p90 {np.percentile(starts,10):.0f}/{np.percentile(starts,50):.0f}/{np.percentile(starts,90):.0f}")
 # per-workgroup timelines (slot 7 = blockIdx.x): idle time between consecutive tiles, start skew
 wg = t[:, 7]
 t0 = t[:, 0].min()
@@ -59,6 +72,11 @@ for w in np.unique(wg):
     lasts.append(r[-1, 5] - t0)
     counts.append(len(r))
     gaps += list(r[1:, 0] - r[:-1, 5])
+wgspan = np.array(lasts) - np.array(firsts)
+print(f"  per-WG span (first tile start -> last tile end): mean {wgspan.mean():.0f} p50 {np.median(wgspan):.0f} p95 {np.percentile(wgspan,95):.0f} max {wgspan.max():.0f}")
+for ntiles in sorted(set(counts)):
+    sel = wgspan[np.array(counts) == ntiles]
+    print(f"    WGs with {ntiles} tiles: {len(sel)}  span mean {sel.mean():.0f} max {sel.max():.0f}")
 print(f"  workgroups {len(firsts)}  tiles/WG mean {np.mean(counts):.2f} min {min(counts)} max {max(counts)}")
 print(f"  first tile start: mean {np.mean(firsts):.0f} max {np.max(firsts):.0f};  last tile end: mean {np.mean(lasts):.0f} min {np.min(lasts):.0f} max {np.max(lasts):.0f}")
 if gaps:
