@@ -84,3 +84,71 @@ def test_two_rank_gloo_size_allgather():
         assert t == 2.0              # max over ranks of (1 + rank)
         seen.update(range(start, end))
     assert seen == set(range(n))
+
+
+# ---------------------------------------------------------------- compressed all-gather
+class _OracleCodec:
+    """CPU stand-in for the GPU float codec (test infrastructure): same interface, oracle inside."""
+
+    def __init__(self, O):
+        self.O = O
+
+    def compress(self, tensors):
+        O = self.O
+        arch = [O.float_compress(O.BFLOAT16, t.view(torch.int16).numpy().view(np.uint16), 10) for t in tensors]
+        cap = max(O.float_max_compressed_size(O.BFLOAT16, t.numel()) for t in tensors)
+        comp = torch.zeros((len(arch), cap), dtype=torch.uint8)
+        for i, a in enumerate(arch):
+            comp[i, : a.size] = torch.from_numpy(a.copy())
+        return comp, torch.tensor([a.size for a in arch], dtype=torch.int32)
+
+    def decompress(self, rows, outs):
+        O = self.O
+        for r, o in zip(rows, outs):
+            rc, w, _ = O.float_decompress(O.BFLOAT16, r.numpy(), 10, o.numel())
+            assert rc == 0 and w.size == o.numel()
+            o.view(torch.int16).copy_(torch.from_numpy(w.view(np.int16).copy()))
+        return torch.ones((len(rows),), dtype=torch.uint8)
+
+
+def _cag_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+
+    import oracle as O
+    from dietgpu_amd import distributed as D
+
+    D.init(backend="gloo")
+    g = torch.Generator().manual_seed(100 + rank)
+    mine = [torch.randn(5000 + 16 * i, generator=g).to(torch.bfloat16) for i in range(3)]
+    gathered, stats = D.compressed_all_gather(mine, codec=_OracleCodec(O))
+    ok = True
+    for r in range(world):
+        gr = torch.Generator().manual_seed(100 + r)
+        want = [torch.randn(5000 + 16 * i, generator=gr).to(torch.bfloat16) for i in range(3)]
+        for a, b in zip(gathered[r], want):
+            ok = ok and torch.equal(a.view(torch.int16), b.view(torch.int16))
+    dist.barrier()
+    q.put((rank, ok, stats))
+    dist.destroy_process_group()
+
+
+def test_compressed_all_gather_world2():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cag_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, stats in res:
+        assert ok, f"rank {rank}: gathered tensors differ"
+        # bf16 N(0,1): the wire carries fewer bytes than the raw tensors
+        assert stats["payload_bytes"] < stats["raw_bytes"]
+        assert stats["wire_bytes"] < stats["raw_bytes"]
