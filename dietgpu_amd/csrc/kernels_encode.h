@@ -24,19 +24,22 @@
 //     juggling or branch issue slots are spent (integer VALU ops issue at ~4
 //     cycles per wave-instruction per SIMD on this chip, LDS/VMEM instructions
 //     at 10-15: every instruction in the row counts).
-//   * Each half-wave emits its u16 words into an LDS stage.  A workgroup (4
-//     waves = 8 blocks = one "tile") publishes the padded word count of its
-//     tile and obtains its archive offset with a decoupled look-back over the
-//     preceding tiles of the same batch element, then copies the stage to its
-//     final place with 16-byte stores.  There is no scratch buffer in HBM and
-//     no coalesce pass.
-//   * Tiles are handed out by an atomic ticket in TILE-MAJOR order (ticket t ->
-//     element t % B, tile t / B).  A tile's predecessors always hold smaller
-//     tickets, so it only ever waits on tiles that have already started: the
+//   * Each half-wave emits its u16 words into an LDS stage (worst case for raw
+//     bytes; 1024 words + a spill slot in temp memory for floats, see
+//     encStageCap).  A workgroup (4 waves = 8 blocks = one "tile") publishes the
+//     padded word count of its tile and obtains its archive offset with a
+//     decoupled look-back over the preceding tiles of the same batch element,
+//     then copies the stage to its final place with 16-byte stores.  There is no
+//     per-block scratch buffer in HBM and no coalesce pass.
+//   * Workgroups are persistent (as many as fit on the chip) and draw tiles from
+//     atomic tickets in TILE-MAJOR order (ticket t -> element t % B, tile t / B).
+//     A tile's predecessors always hold smaller tickets, so it only ever waits
+//     on tiles that have already been drawn by a running workgroup: the
 //     look-back cannot deadlock whatever order the hardware dispatches
-//     workgroups in.  And with a batch of B elements the predecessor started B
-//     tickets earlier, i.e. it has usually finished long before: measured with
-//     element-major order the look-back wait was 17 % of a tile's lifetime.
+//     workgroups in and however many of them are resident.  With a batch of B
+//     elements the predecessor started B tickets earlier, i.e. it has usually
+//     finished long before: measured with element-major order the look-back
+//     wait was 17 % of a tile's lifetime.
 //   * Hand-off words are single 8-byte {status, value} granules written and
 //     polled with relaxed agent-scope atomics (write-through sc1 stores /
 //     L1-bypassing loads), the placement-independent form for gfx950's
