@@ -39,6 +39,7 @@ _SIGS = {
     "dgpu_prof_enable": (None, [i32]),
     "dgpu_prof_reset": (None, []),
     "dgpu_prof_summary": (i32, [C.c_char_p, sz]),
+    "dgpu_debug_set_absent_workgroups": (None, [u32]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -528,6 +529,8 @@ int launchEncode(int P, uint32_t ft, const EncodeArgs& a, uint32_t grid, hipStre
 
 uint32_t tilesFor(uint32_t maxSize) { return divUp(divUp(maxSize, kBlockSize), kBlocksPerTile); }
 
+uint32_t absentWorkgroupModulo();  // test hook, defined with the C ABI below
+
 // Library-owned arrival counters for the histogram -> normalisation hand-off
 // (HistFuse): 65536 u32 per (device, stream), zero at rest -- the kernel that uses
 // them puts them back to zero.  Keyed by stream because calls on one stream are
@@ -579,6 +582,7 @@ int encodeCommon(
   DGPU_ALLOC(table, uint4, arena, (size_t)B * kNumSymbols);
   DGPU_ALLOC(tileDesc, uint64_t, arena, (size_t)B * std::max(maxTiles, 1u));
   DGPU_ALLOC(ticket, uint32_t, arena, 64 * kTicketStride);
+  DGPU_ALLOC(claims, uint32_t, arena, (size_t)B * std::max(maxTiles, 1u));
 
   NormalizeArgs n;
   n.sizes = in;
@@ -598,6 +602,8 @@ int encodeCommon(
   n.tileDesc = tileDesc;
   n.maxTiles = maxTiles;
   n.ticket = ticket;
+  n.claims = claims;
+  n.numInBatch = B;
 
   if (!hist_dev) {
     dim3 grid(histPartsFor(B, maxSize * wordBytes), B);
@@ -644,6 +650,8 @@ int encodeCommon(
     e.numTickets = B * maxTiles;
     e.tileDesc = tileDesc;
     e.ticket = ticket;
+    e.claims = claims;
+    e.absentModulo = absentWorkgroupModulo();
     e.spill = spill;
     e.outSize = outSize_dev;
     e.useChecksum = (useChecksum && floatType) ? 1 : 0;
@@ -857,6 +865,14 @@ int dgpu_debug_set_phase_buffer(void* buf_dev) {
 }
 #endif
 
+static std::atomic<uint32_t> g_absentModulo{0};
+}  // extern "C"
+namespace {
+uint32_t absentWorkgroupModulo() { return g_absentModulo.load(); }
+}  // namespace
+extern "C" {
+void dgpu_debug_set_absent_workgroups(uint32_t modulo) { g_absentModulo.store(modulo); }
+
 void dgpu_prof_enable(int on) {
   ProfState& p = prof();
   std::lock_guard<std::mutex> g(p.mu);
@@ -918,6 +934,7 @@ static size_t encodeTempBytes(uint32_t B, uint32_t maxBytes, uint32_t wordBytes,
   t += alignUp((size_t)B * kNumSymbols * 16, kTempAlign);                         // encoder table
   t += alignUp((size_t)B * tiles * 8, kTempAlign);                                // tile descriptors
   t += alignUp((size_t)64 * kTicketStride * 4, kTempAlign);                       // ticket counters
+  t += alignUp((size_t)B * tiles * 4, kTempAlign);                                // tile claim words
   if (spills) {
     // spill slots of the persistent encoder workgroups (bounded by what fits on the chip)
     size_t perCu = (160u * 1024u) / encLdsBytes(9, true);
@@ -1251,6 +1268,8 @@ int dgpu_ans_calc_weights(
   n.tileDesc = nullptr;
   n.maxTiles = 0;
   n.ticket = nullptr;
+  n.claims = nullptr;
+  n.numInBatch = numInBatch;
   hipLaunchKernelGGL(k_normalize, dim3(numInBatch), dim3(256), 0, (hipStream_t)stream, n);
   DGPU_HIP(hipGetLastError());
   return DGPU_OK;

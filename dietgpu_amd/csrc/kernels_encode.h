@@ -49,9 +49,12 @@
 #include "format.h"
 #include "kernels_stats.h"
 
-#ifndef DGPU_STATIC_SCHEDULE
-#define DGPU_STATIC_SCHEDULE 0
+// Tile schedule of the encoder: 0 = dynamic tickets (eight counters), 1 = static map WITHOUT
+// residency protection (analysis only, can deadlock), 2 = static map with claim words (default).
+#ifndef DGPU_SCHEDULE
+#define DGPU_SCHEDULE 2
 #endif
+#define DGPU_STATIC_SCHEDULE (DGPU_SCHEDULE == 1)
 #ifndef DGPU_ENC_ASM_STEP
 #define DGPU_ENC_ASM_STEP 0
 #endif
@@ -104,6 +107,8 @@ struct EncodeArgs {
   uint32_t numTickets;       // B * maxTiles
   uint64_t* tileDesc;        // [B][maxTiles], zeroed before launch
   uint32_t* ticket;          // kTicketCounters counters, kTicketStride words apart, zeroed before launch
+  uint32_t* claims;          // [maxTiles][B] tile claim words, zeroed before launch (DGPU_SCHEDULE 2)
+  uint32_t absentModulo;     // test hook: workgroups with index % absentModulo == 1 start ~0.5 ms late (0 = off)
   uint16_t* spill;           // [gridDim.x][kBlocksPerTile][encSpillSlotWords(P)] (kSpill kernels only)
   uint32_t* outSize;         // [B] nullable
   uint32_t useChecksum;      // float header only
@@ -492,18 +497,89 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   const uint32_t dummyLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(sRing + kBlocksPerTile * 512u) + tid * 2u;
   uint16_t* spillSlot = kSpill ? a.spill + ((size_t)blockIdx.x * kBlocksPerTile + hw) * encSpillSlotWords(P) : nullptr;
 
-  // Persistent workgroup: tiles are drawn from the ticket counter until it runs out.
-#if DGPU_STATIC_SCHEDULE  // analysis only: UNSAFE unless every workgroup of the grid is resident
+#if DGPU_SCHEDULE == 2
+  // Persistent workgroups, STATIC tile map with claim words.  Workgroup w owns the
+  // tickets w, w + G, w + 2G, ... (G = gridDim.x; ticket t -> element t % B, tile
+  // t / B) and walks them in order: no ticket atomic on the critical path and a
+  // perfectly regular round structure (106 -> 93 us for the kernel).  A plain
+  // static map would hang whenever part of the grid is not resident (another
+  // kernel holding CUs): running workgroups would spin in the look-back on tiles
+  // whose owner never starts.  Hence one claim word per tile:
+  //   * at its start a workgroup claims ALL its tiles (CAS 0 -> w + 1, fire and
+  //     forget), so every tile of a running workgroup is claimed from then on;
+  //   * before encoding a tile it makes sure the element's previous tile is
+  //     claimed by somebody; an unclaimed one (its owner is not running) it
+  //     claims itself and encodes FIRST, recursively down the element;
+  //   * a workgroup that finds one of its tiles claimed by someone else skips it.
+  // Every tile is encoded exactly once (the CAS decides), and a workgroup only
+  // ever waits (look-back) on tiles that are claimed, i.e. whose encoder is
+  // running or done and was itself started only after ITS predecessor was
+  // claimed: the tile with the smallest (element-wise) index among the
+  // unfinished ones never waits, so there is no deadlock at any residency.
+  // With the whole grid resident nobody steals and this IS the static schedule.
+  if (a.absentModulo && blockIdx.x % a.absentModulo == 1u) {
+    // test hook: a workgroup that becomes resident late (~0.5 ms after the others)
+    for (int i = 0; i < 150; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  const uint32_t me = blockIdx.x + 1u;
+  const uint32_t B = a.numInBatch;
+  auto claimLoad = [&](uint32_t idx) -> uint32_t {
+    return __hip_atomic_load(a.claims + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto claimTry = [&](uint32_t idx) -> bool {  // true if this workgroup now owns idx
+    uint32_t expected = 0;
+    return __hip_atomic_compare_exchange_strong(a.claims + idx, &expected, me, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+  };
+  bool firstOwned = false;
+  if (tid == 0 && blockIdx.x < a.numTickets) firstOwned = claimTry(blockIdx.x);
+  for (uint32_t t = blockIdx.x + (tid + 1u) * gridDim.x; t < a.numTickets; t += 256u * gridDim.x) {
+    (void)claimTry(t);  // later tickets: result looked up when the ticket comes up
+  }
+  for (uint32_t ticket0 = blockIdx.x; ticket0 < a.numTickets; ticket0 += gridDim.x) {
+    const uint32_t tile0 = ticket0 / B;
+    const uint32_t b = ticket0 - tile0 * B;
+    {
+      const uint32_t tilesOfB = divUp(divUp(a.in.size(b), kBlockSize), kBlocksPerTile);
+      if (tile0 >= tilesOfB) continue;  // uniform (ragged batch)
+    }
+    if (tid == 0) {
+      bool mine = (ticket0 == blockIdx.x) ? firstOwned : (claimLoad(ticket0) == me);
+      uint32_t lo = tile0 + 1u;  // empty range: the tile was taken over by somebody else
+      if (mine) {
+        lo = tile0;
+        while (lo > 0u) {
+          const uint32_t idx = (lo - 1u) * B + b;
+          uint32_t p = claimLoad(idx);
+          for (int spin = 0; p == 0u && spin < 4; ++spin) {  // give a running owner's claim time to land
+            __builtin_amdgcn_s_sleep(32);
+            p = claimLoad(idx);
+          }
+          if (p != 0u) break;
+          if (!claimTry(idx)) break;
+          --lo;
+        }
+      }
+      sh->ticket = lo;
+    }
+    ldsBarrier();
+    const uint32_t tileLo = sh->ticket;
+    if (tileLo > tile0) {
+      ldsBarrier();  // everybody has read sh->ticket
+      continue;
+    }
+   for (uint32_t tile = tileLo; tile <= tile0; ++tile) {
+    const uint32_t ticket = tile * B + b;
+#elif DGPU_SCHEDULE == 1  // analysis only: UNSAFE unless every workgroup of the grid is resident
   for (uint32_t ticket = blockIdx.x; ticket < a.numTickets; ticket += gridDim.x) {
 #else
+  // Persistent workgroup: tiles are drawn from ticket counters until they run out.
   // Several ticket counters instead of one (1536 workgroups queueing on a single
   // address cost ~12 us at kernel start): with C counters, C the largest power
   // of two <= kTicketCounters that divides B, counter x hands out the tickets
   // x, x + C, x + 2C, ...  A ticket's predecessors t - B, t - 2B, ... are in its
   // own residue class and smaller tickets of a class are always drawn first, so
-  // the no-deadlock argument is unchanged.  A workgroup starts at the counter
-  // matching the XCD it runs on (workgroups are dealt to XCDs round robin, so
-  // the counters drain evenly) and moves on when a counter is exhausted.
+  // a tile only ever waits on tiles drawn by running workgroups.
   uint32_t numCounters = kTicketCounters;
   while (a.numInBatch % numCounters) numCounters >>= 1;
   uint32_t myCounter = 0;
@@ -535,18 +611,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 #ifdef DGPU_PHASE_TIMING
     if (threadIdx.x == 0 && g_phaseBuf) g_phaseBuf[(size_t)phaseSlot * 8 + 7] = blockIdx.x;
 #endif
+#if DGPU_SCHEDULE != 2
     const uint32_t tile = ticket / a.numInBatch;
     const uint32_t b = ticket - tile * a.numInBatch;
+#endif
 
     const uint32_t size = a.in.size(b);
     const uint32_t nb = divUp(size, kBlockSize);
     const uint32_t numTiles = divUp(nb, kBlocksPerTile);
+#if DGPU_SCHEDULE != 2
     if (tile >= numTiles) {  // uniform; nobody reads sh->ticket after the barrier below
-#if !DGPU_STATIC_SCHEDULE
+#if DGPU_SCHEDULE == 0
       ldsBarrier();
 #endif
       continue;
     }
+#endif
 
     sTable[tid] = a.encTable[b * kNumSymbols + tid];
     ldsBarrier();
@@ -699,6 +779,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       for (uint32_t i = hl; i < vecs; i += 32u) streamStore<DGPU_NT_ENC_STORES != 0>(&dst[i], s4[i]);
     }
     DGPU_PHASE(5);
+#if DGPU_SCHEDULE == 2
+   }  // tiles [tileLo, tile0] of element b
+#endif
   }
 }
 

@@ -65,6 +65,8 @@ struct NormalizeArgs {
   uint64_t* tileDesc;        // [B][maxTiles] nullable
   uint32_t maxTiles;
   uint32_t* ticket;          // nullable
+  uint32_t* claims;          // [maxTiles][numInBatch] nullable (encoder's tile claim words)
+  uint32_t numInBatch;
 };
 
 // One 256-thread workgroup normalises batch element b.  kCoherent: the partial
@@ -90,7 +92,10 @@ __device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const u
   uint32_t pdf = 0, cdf = 0;
 
   if (a.tileDesc) {
-    for (uint32_t i = tid; i < a.maxTiles; i += 256u) a.tileDesc[(size_t)b * a.maxTiles + i] = 0;
+    for (uint32_t i = tid; i < a.maxTiles; i += 256u) {
+      a.tileDesc[(size_t)b * a.maxTiles + i] = 0;
+      if (a.claims) a.claims[(size_t)i * a.numInBatch + b] = 0;
+    }
     if (b == 0 && tid < 64u) a.ticket[tid * 32u] = 0;  // the encoder's ticket counters (<= 64, 32 words apart)
   }
 

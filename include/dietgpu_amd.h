@@ -231,6 +231,13 @@ void dgpu_prof_reset(void);
  * (synchronises on the recorded events). Returns length, or -1 if cap is too small. */
 int dgpu_prof_summary(char* buf, size_t cap);
 
+/* Test hook: makes every encoder workgroup whose index is congruent to 1 modulo
+ * `modulo` start about half a millisecond after the others (0 = off, the
+ * default).  It emulates a grid that is only partly resident at first -- other
+ * kernels holding compute units -- so that tests can exercise the path in which
+ * running workgroups take over the tiles of workgroups that have not started. */
+void dgpu_debug_set_absent_workgroups(uint32_t modulo);
+
 #ifdef __cplusplus
 }
 #endif

@@ -366,6 +366,35 @@ def test_float_incompressible_exponents(dg, ft, prob_bits):
         assert (tensor_to_words(ft, o) == w).all()
 
 
+@pytest.mark.parametrize("modulo", [2, 3, 7])
+def test_encoder_with_absent_workgroups(dg, modulo):
+    # The encoder's static tile map must not depend on the whole grid being resident: with a
+    # part of the workgroups starting late (test hook), the running ones take over the tiles
+    # they depend on, the late ones pick up what is left -- and the archives stay
+    # byte-identical.  Many tiles per element so that take-over chains form.
+    L = dg.lib()
+    rng = np.random.default_rng(50 + modulo)
+    ns = [4096 * 8 * 40 + 77, 4096 * 8 * 23, 4096 * 8 * 64, 5, 4096 * 8 * 31 + 4095, 4096 * 8 * 9]
+    ws = [refgen.generate_floats(O.BFLOAT16, n) for n in ns]
+    xs = [refgen.generate_symbols(n, 20.0) if hasattr(refgen, "generate_symbols")
+          else rng.integers(0, 64, n, dtype=np.uint8) for n in (4096 * 8 * 50 + 1, 4096 * 8 * 17, 300)]
+    L.dgpu_debug_set_absent_workgroups(modulo)
+    try:
+        ts = [words_to_tensor(O.BFLOAT16, w) for w in ws]
+        comp, sizes, _ = dg.compress_data(True, ts, False, prob_bits=10)
+        hs = sizes.cpu().numpy()
+        hc = comp.cpu().numpy()
+        got_raw = gpu_ans_encode(dg, xs, 10)
+    finally:
+        L.dgpu_debug_set_absent_workgroups(0)
+    for i, w in enumerate(ws):
+        want = O.float_compress(O.BFLOAT16, w, 10)
+        assert hs[i] == want.size and (hc[i, : hs[i]] == want).all(), (modulo, i)
+    for x, g in zip(xs, got_raw):
+        want = O.ans_encode(x, 10)
+        assert g.size == want.size and (g == want).all()
+
+
 @pytest.mark.parametrize("ft", [O.FLOAT16, O.BFLOAT16, O.FLOAT32])
 def test_float_unaligned_io(dg, ft):
     # inputs / outputs that are only float-word aligned (scalar paths)
