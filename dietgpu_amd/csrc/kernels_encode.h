@@ -424,7 +424,12 @@ __device__ __forceinline__ uint32_t encodeRows(
     // 8 chunks of 16 rows; chunk c+1 is in flight in registers while chunk c is
     // consumed from the LDS ring (same wave writes and reads it: LDS ops of one
     // wave execute in order, no barrier needed).
-    constexpr int kAhead = 4;
+    // table entries in flight ahead of the row being encoded (measured: 2 beats 4 --
+    // eight registers fewer matter more than the extra LDS latency cover at 6 waves per SIMD)
+#ifndef DGPU_ENC_AHEAD
+#define DGPU_ENC_AHEAD 2
+#endif
+    constexpr int kAhead = DGPU_ENC_AHEAD;
     typename ChunkSource<FT>::Raw cur = src.load(0, hl);
 #pragma unroll 1
     for (uint32_t c = 0; c < kRowsPerBlock / 16; ++c) {
