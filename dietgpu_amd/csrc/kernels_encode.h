@@ -436,13 +436,22 @@ __device__ __forceinline__ uint32_t encodeRows(
       const uint4 symbols = src.consume(cur, c, hl);
       *(uint4*)(ring + hl * 16u) = symbols;
       if (c + 1 < kRowsPerBlock / 16) cur = src.load(c + 1, hl);
-      // LDS addresses of the 16 table entries (table + sym * 16), formed right at the load
-      uint32_t toff[16];
+      // LDS addresses of the table entries (table + sym * 16), formed right at the
+      // symbol load; kSymAhead symbols and kAhead table entries are in flight.
+      // (Reading all 16 symbols of the chunk up front costs 16 live registers.)
+#ifndef DGPU_ENC_SYM_AHEAD
+#define DGPU_ENC_SYM_AHEAD 4
+#endif
+      constexpr int kSymAhead = DGPU_ENC_SYM_AHEAD;
+      static_assert(kSymAhead > kAhead && kSymAhead <= 16, "a symbol slot is reused only after its table load was issued");
+      auto symAddr = [&](int r) -> uint32_t {
+        uint32_t t = tableLds + ((uint32_t)ring[r * 32 + hl] << 4);
+        asm volatile("" : "+v"(t));  // keep the scaled address; do not re-derive it (with a mask) at the use
+        return t;
+      };
+      uint32_t toff[kSymAhead];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        toff[r] = tableLds + ((uint32_t)ring[r * 32 + hl] << 4);
-        asm volatile("" : "+v"(toff[r]));  // keep the scaled address; do not re-derive it (with a mask) at the use
-      }
+      for (int r = 0; r < kSymAhead; ++r) toff[r] = symAddr(r);
       uint4 e[kAhead];
 #pragma unroll
       for (int r = 0; r < kAhead; ++r) e[r] = ldsTableEntry(toff[r]);
@@ -450,7 +459,8 @@ __device__ __forceinline__ uint32_t encodeRows(
       for (int r = 0; r < 16; ++r) {
         if (r % kFlushRows == 0) makeRoom();
         const uint4 cur_e = e[r % kAhead];
-        if (r + kAhead < 16) e[r % kAhead] = ldsTableEntry(toff[r + kAhead]);
+        if (r + kAhead < 16) e[r % kAhead] = ldsTableEntry(toff[(r + kAhead) % kSymAhead]);
+        if (r + kSymAhead < 16) toff[r % kSymAhead] = symAddr(r + kSymAhead);
 #if DGPU_ENC_ASM_STEP
         stepFullAsm(cur_e);
 #else
