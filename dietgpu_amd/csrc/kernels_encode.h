@@ -31,10 +31,10 @@
 //     decoupled look-back over the preceding tiles of the same batch element,
 //     then copies the stage to its final place with 16-byte stores.  There is no
 //     per-block scratch buffer in HBM and no coalesce pass.
-//   * Workgroups are persistent (as many as fit on the chip) and draw tiles from
-//     atomic tickets in TILE-MAJOR order (ticket t -> element t % B, tile t / B).
-//     A tile's predecessors always hold smaller tickets, so it only ever waits
-//     on tiles that have already been drawn by a running workgroup: the
+//   * Workgroups are persistent (as many as fit on the chip) and encode tiles in
+//     TILE-MAJOR ticket order (ticket t -> element t % B, tile t / B) under a
+//     static map protected by per-tile claim words, see k_ans_encode.  A tile
+//     only ever waits on tiles that are claimed by a running workgroup: the
 //     look-back cannot deadlock whatever order the hardware dispatches
 //     workgroups in and however many of them are resident.  With a batch of B
 //     elements the predecessor started B tickets earlier, i.e. it has usually
