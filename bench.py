@@ -44,9 +44,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6290 measured copy
 
 
-def make_workload(kind, batch, seed, device):
+def make_workload(kind, batch, seed, device, n=512 * 1024):
     """Returns (tensors-as-2D tensor, float type or 0, element bytes, prob_bits, description)."""
-    n = 512 * 1024
     if kind == "bf16":
         g = torch.Generator(device=device).manual_seed(seed)
         t = torch.randn((batch, n), generator=g, device=device, dtype=torch.float32).to(torch.bfloat16)
@@ -240,6 +239,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="bf16", choices=["bf16", "u8", "fp16"])
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--elems", type=int, default=512 * 1024,
+                    help="elements per tensor for the float workloads (default = BASELINE configs: 524288)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timeline", action="store_true",
                     help="only the timed steps (no per-phase timing / kernel profile): for rocprofv3 timelines")
@@ -259,7 +260,7 @@ def main():
 
         D.init(backend="nccl", device=device)  # "nccl" is RCCL on ROCm
 
-    data, ft, _, prob_bits, desc = make_workload(args.workload, args.batch, 1234 + rank, device)
+    data, ft, _, prob_bits, desc = make_workload(args.workload, args.batch, 1234 + rank, device, args.elems)
     codec = Codec(dg, data, ft, prob_bits)
 
     def fence():
