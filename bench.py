@@ -241,6 +241,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--elems", type=int, default=512 * 1024,
                     help="elements per tensor for the float workloads (default = BASELINE configs: 524288)")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timeline", action="store_true",
                     help="only the timed steps (no per-phase timing / kernel profile): for rocprofv3 timelines")
@@ -250,15 +251,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # DGPU_BENCH_ONE_DEVICE=1 (with --dist-backend gloo): every rank on GPU 0 -- lets the N > 1 code path
+    # be exercised on a single-GPU box; never used for measurements
+    dev_index = 0 if os.environ.get("DGPU_BENCH_ONE_DEVICE") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     import dietgpu_amd as dg
     from dietgpu_amd import distributed as D
 
     if distributed:
         import torch.distributed as dist
 
-        D.init(backend="nccl", device=device)  # "nccl" is RCCL on ROCm
+        D.init(backend=args.dist_backend, device=device)  # "nccl" is RCCL on ROCm
 
     data, ft, _, prob_bits, desc = make_workload(args.workload, args.batch, 1234 + rank, device, args.elems)
     codec = Codec(dg, data, ft, prob_bits)
@@ -330,7 +334,9 @@ def main():
             ach = kernels[dom]["algorithmic_GBps"]
             roofline = {
                 "bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": measured_traffic(args.workload, dom),
+                "frac": round(ach / HBM_PEAK_GBPS, 4),
+                # the PMC passes were taken on the default shape only
+                "traffic": measured_traffic(args.workload, dom) if (args.batch == 256 and args.elems == 512 * 1024) else None,
                 "avg_us": kernels[dom]["avg_us"],
                 "algorithmic_bytes": algorithmic_bytes(dom, codec, comp_total),
                 "traffic_source": "profiles/r01_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
