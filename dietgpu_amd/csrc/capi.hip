@@ -717,18 +717,24 @@ int floatCompressImpl(
 }
 
 template <int P, uint32_t FT>
-int launchDecodePF(const DecodeArgs& a, dim3 grid, hipStream_t stream) {
-  DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode<P, FT>), grid, dim3(kDecThreads), decLdsBytes(P), stream, a);
+int launchDecodePF(const DecodeArgs& a, uint32_t tileBlocks, dim3 grid, hipStream_t stream) {
+  if (tileBlocks == kDecBlocksPerSmallTile) {
+    DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode<P, FT, kDecBlocksPerSmallTile>), grid, dim3(kDecBlocksPerSmallTile * 32u),
+                decLdsBytes(P, kDecBlocksPerSmallTile), stream, a);
+  } else {
+    DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode<P, FT, kDecBlocksPerTile>), grid, dim3(kDecBlocksPerTile * 32u),
+                decLdsBytes(P, kDecBlocksPerTile), stream, a);
+  }
   DGPU_HIP(hipGetLastError());
   return DGPU_OK;
 }
 
 template <uint32_t FT>
-int launchDecodeF(int P, const DecodeArgs& a, dim3 grid, hipStream_t stream) {
+int launchDecodeF(int P, const DecodeArgs& a, uint32_t tileBlocks, dim3 grid, hipStream_t stream) {
   switch (P) {
-    case 9: return launchDecodePF<9, FT>(a, grid, stream);
-    case 10: return launchDecodePF<10, FT>(a, grid, stream);
-    default: return launchDecodePF<11, FT>(a, grid, stream);
+    case 9: return launchDecodePF<9, FT>(a, tileBlocks, grid, stream);
+    case 10: return launchDecodePF<10, FT>(a, tileBlocks, grid, stream);
+    default: return launchDecodePF<11, FT>(a, tileBlocks, grid, stream);
   }
 }
 
@@ -772,7 +778,10 @@ int decodeImpl(
     }
   }
 
-  const uint32_t maxTiles = std::max(1u, divUp(divUp(maxCapacity, kBlockSize), kDecBlocksPerTile));
+  // elements of up to 8 blocks: 4-block workgroups (see kDecBlocksPerSmallTile)
+  const uint32_t maxBlocks = divUp(maxCapacity, kBlockSize);
+  const uint32_t tileBlocks = maxBlocks <= 8u ? kDecBlocksPerSmallTile : kDecBlocksPerTile;
+  const uint32_t maxTiles = std::max(1u, divUp(maxBlocks, tileBlocks));
   {
     DecodeArgs d;
     d.in = in;
@@ -782,10 +791,10 @@ int decodeImpl(
     d.outSize = useChecksum ? sizesForChecksum : outSize_dev;
     dim3 grid(maxTiles, B);
     int rc;
-    if (ft == 0) rc = launchDecodeF<0>(P, d, grid, stream);
-    else if (ft == kFloat16) rc = launchDecodeF<kFloat16>(P, d, grid, stream);
-    else if (ft == kBFloat16) rc = launchDecodeF<kBFloat16>(P, d, grid, stream);
-    else rc = launchDecodeF<kFloat32>(P, d, grid, stream);
+    if (ft == 0) rc = launchDecodeF<0>(P, d, tileBlocks, grid, stream);
+    else if (ft == kFloat16) rc = launchDecodeF<kFloat16>(P, d, tileBlocks, grid, stream);
+    else if (ft == kBFloat16) rc = launchDecodeF<kBFloat16>(P, d, tileBlocks, grid, stream);
+    else rc = launchDecodeF<kFloat32>(P, d, tileBlocks, grid, stream);
     if (rc) return rc;
   }
 

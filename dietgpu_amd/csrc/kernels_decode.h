@@ -137,9 +137,12 @@ constexpr uint32_t kGroupRows = 8;
 // rings + 8 KiB LUT (P = 10) lets 4 workgroups = 32 wavefronts (the maximum)
 // reside on a CU.
 constexpr uint32_t kDecBlocksPerTile = 16;
-constexpr uint32_t kDecThreads = kDecBlocksPerTile * 32u;
-__host__ __device__ constexpr uint32_t decLdsBytes(int P) {
-  return (8u << P) + kDecBlocksPerTile * kRingBytes;
+// Batches of small elements (a few blocks each) use 4-block workgroups instead:
+// a 16-block workgroup would leave most of its waves without a block while
+// still holding its LDS and wave slots.
+constexpr uint32_t kDecBlocksPerSmallTile = 4;
+__host__ __device__ constexpr uint32_t decLdsBytes(int P, uint32_t tileBlocks) {
+  return (8u << P) + tileBlocks * kRingBytes;
 }
 
 template <int P, uint32_t FT, bool kFull>
@@ -258,12 +261,13 @@ __device__ __forceinline__ void decodeBlock(
   }
 }
 
-// grid = (maxTiles, B), 512 threads, LDS = 16 word rings + 64-bit LUT.
-template <int P, uint32_t FT>
-__global__ __launch_bounds__(kDecThreads) void k_ans_decode(DecodeArgs a) {
+// grid = (maxTiles, B), 32 threads per block of the tile (512 or 128), LDS = word rings + 64-bit LUT.
+template <int P, uint32_t FT, uint32_t kTileBlocks>
+__global__ __launch_bounds__(kTileBlocks * 32u) void k_ans_decode(DecodeArgs a) {
+  constexpr uint32_t kDecThreads = kTileBlocks * 32u;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   // rings: 16 x 2 KiB at LDS offset 0 (2 KiB aligned), then the LUT
-  uint2* sLut = (uint2*)(smem + kDecBlocksPerTile * kRingBytes);
+  uint2* sLut = (uint2*)(smem + kTileBlocks * kRingBytes);
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(kDecThreads) void k_ans_decode(DecodeArgs a) {
     if (a.outSuccess) a.outSuccess[b] = success ? 1 : 0;
     if (a.outSize) a.outSize[b] = total;
   }
-  if (!success || tile * kDecBlocksPerTile >= nb) return;
+  if (!success || tile * kTileBlocks >= nb) return;
 
   // Decode LUT, built by the workgroup itself from the archive's pdf table (no
   // separate table kernel / LUT round trip through HBM):
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(kDecThreads) void k_ans_decode(DecodeArgs a) {
     }
   }
 
-  const uint32_t block = tile * kDecBlocksPerTile + hw;
+  const uint32_t block = tile * kTileBlocks + hw;
   const bool haveBlock = block < nb;
 
   uint32_t state = 0, n = 0, numWords = 0, start = 0;

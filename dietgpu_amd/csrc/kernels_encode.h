@@ -167,7 +167,8 @@ __device__ __forceinline__ uint4 ldsTableEntry(uint32_t addr) {
 //   load(c)    : issue the global loads of chunk c (kept in registers)
 //   consume(r) : turn them into the 16 symbol bytes for the ring; the float
 //                sources also store the non-compressed bytes into the archive
-//   symbolAt(i): scalar path for partial blocks / unaligned inputs
+//   wordAt(i) / splitAt(i, w, valid): scalar path for partial blocks / unaligned inputs
+//                (the load is unconditional so that a group of them overlaps)
 template <uint32_t FT>
 struct ChunkSource;
 
@@ -184,7 +185,8 @@ struct ChunkSource<0> {  // raw bytes: the symbols are the input
     return r;
   }
   __device__ __forceinline__ uint4 consume(const Raw& r, uint32_t, uint32_t) const { return r.v; }
-  __device__ __forceinline__ uint32_t symbolAt(uint32_t i) const { return in[i]; }
+  __device__ __forceinline__ uint32_t wordAt(uint32_t i) const { return in[i]; }
+  __device__ __forceinline__ uint32_t splitAt(uint32_t, uint32_t w, bool) const { return w; }
 };
 
 // v_perm_b32 selectors: {lo.b0, lo.b2, hi.b0, hi.b2} and {lo.b1, lo.b3, hi.b1, hi.b3}
@@ -242,8 +244,8 @@ struct ChunkSource16 {
     streamStore<DGPU_NT_ENC_STORES != 0>(&((uint4*)(nc + c * 512u))[hl], make_uint4(rest[0], rest[1], rest[2], rest[3]));
     return make_uint4(comp[0], comp[1], comp[2], comp[3]);
   }
-  __device__ __forceinline__ uint32_t symbolAt(uint32_t i) const {
-    const uint32_t w = in[i];
+  __device__ __forceinline__ uint32_t wordAt(uint32_t i) const { return in[i]; }
+  __device__ __forceinline__ uint32_t splitAt(uint32_t i, uint32_t w, bool valid) const {
     uint32_t c, r;
     if (FT == kFloat16) {
       c = w >> 8;
@@ -252,7 +254,7 @@ struct ChunkSource16 {
       c = (w >> 7) & 0xffu;
       r = ((w << 1) & 0xfeu) | (w >> 15);
     }
-    nc[i] = (uint8_t)r;
+    if (valid) nc[i] = (uint8_t)r;
     return c;
   }
 };
@@ -306,11 +308,13 @@ struct ChunkSource<kFloat32> {  // 4-byte words: comp byte + 24 non-comp bits (u
     streamStore<DGPU_NT_ENC_STORES != 0>(&((uint4*)(nc1 + c * 512u))[hl], make_uint4(hi[0], hi[1], hi[2], hi[3]));
     return make_uint4(comp[0], comp[1], comp[2], comp[3]);
   }
-  __device__ __forceinline__ uint32_t symbolAt(uint32_t i) const {
-    const uint32_t w = in[i];
+  __device__ __forceinline__ uint32_t wordAt(uint32_t i) const { return in[i]; }
+  __device__ __forceinline__ uint32_t splitAt(uint32_t i, uint32_t w, bool valid) const {
     const uint32_t v = (w << 1) | (w >> 31);
-    nc2[i] = (uint16_t)(v & 0xffffu);
-    nc1[i] = (uint8_t)((v >> 16) & 0xffu);
+    if (valid) {
+      nc2[i] = (uint16_t)(v & 0xffffu);
+      nc1[i] = (uint8_t)((v >> 16) & 0xffu);
+    }
     return v >> 24;
   }
 };
@@ -469,13 +473,34 @@ __device__ __forceinline__ uint32_t encodeRows(
       }
     }
   } else {
+    // Partial blocks, unaligned inputs, a wave with a single block: rows in groups
+    // of kFlushRows, the symbol loads (and, for floats, the non-compressed stores)
+    // of a whole group issued before its first step, so a group costs one memory
+    // round trip instead of one per row.
 #pragma unroll 1
-    for (uint32_t row = 0; row < maxRows; ++row) {
-      if (row % kFlushRows == 0) makeRoom();
-      const uint32_t i = row * 32u + hl;
-      const bool valid = i < n;
-      const uint32_t sym = valid ? src.symbolAt(i) : 0u;
-      step(table[sym], valid);
+    for (uint32_t row0 = 0; row0 < maxRows; row0 += kFlushRows) {
+      makeRoom();
+      uint32_t word[kFlushRows];
+#pragma unroll
+      for (uint32_t j = 0; j < kFlushRows; ++j) {
+        const uint32_t i = (row0 + j) * 32u + hl;
+        word[j] = src.wordAt(i < n ? i : 0u);  // unconditional (index 0 is always readable, see the caller)
+      }
+      // table entries two rows ahead of the dependent chain, as in the full path
+      uint32_t taddr[kFlushRows];
+#pragma unroll
+      for (uint32_t j = 0; j < kFlushRows; ++j) {
+        const uint32_t i = (row0 + j) * 32u + hl;
+        taddr[j] = tableLds + ((src.splitAt(i, word[j], i < n) & 0xffu) << 4);
+      }
+      uint4 ent[2] = {ldsTableEntry(taddr[0]), ldsTableEntry(taddr[1])};
+#pragma unroll
+      for (uint32_t j = 0; j < kFlushRows; ++j) {
+        const uint32_t i = (row0 + j) * 32u + hl;
+        const uint4 cur_e = ent[j % 2u];
+        if (j + 2u < kFlushRows) ent[j % 2u] = ldsTableEntry(taddr[j + 2u]);
+        if (row0 + j < maxRows) step(cur_e, i < n);  // uniform condition
+      }
     }
   }
   // The copy-out reads the slot back through other lanes of this wave, after two
@@ -686,7 +711,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         (((uintptr_t)in & 15u) == 0);
 
     ChunkSource<FT> src;
-    src.init(in, archive, size, block);
+    src.init(in, archive, size, haveBlock ? block : 0u);  // an idle half reads (and discards) word 0 of block 0
 
     uint32_t state;
     uint32_t words;        // words left in the LDS stage

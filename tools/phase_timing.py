@@ -26,13 +26,15 @@ import bench
 lib = C.CDLL(DBG)
 dev = torch.device("cuda:0")
 wl = sys.argv[1] if len(sys.argv) > 1 else "bf16"
-data, ft, _, P, desc = bench.make_workload(wl, 256, 1234, dev)
+PT_B = int(os.environ.get("DGPU_PT_BATCH", "256"))
+PT_N = int(os.environ.get("DGPU_PT_ELEMS", str(512 * 1024)))
+data, ft, _, P, desc = bench.make_workload(wl, PT_B, 1234, dev, PT_N)
 codec = bench.Codec(dg, data, ft, P)
 codec.lib = dg.lib()
 for _ in range(3):
     codec.step()
 torch.cuda.synchronize()
-ntiles = 256 * 64
+ntiles = max(256 * 64, PT_B * ((PT_N + 32767) // 32768) + 64)
 buf = torch.zeros((ntiles, 8), dtype=torch.int64, device=dev)
 assert lib.dgpu_debug_set_phase_buffer(C.c_void_p(buf.data_ptr())) == 0
 codec.encode()
@@ -40,7 +42,7 @@ torch.cuda.synchronize()
 t = buf.cpu().numpy()
 slot = np.arange(t.shape[0])
 keep = t[:, 0] != 0
-elem = (slot % 256)[keep]
+elem = (slot % PT_B)[keep]
 t = t[keep]
 print("tiles whose element b has b % 8 == XCD of the workgroup (blockIdx % 8):",
       int(((elem % 8) == (t[:, 7] % 8)).sum()), "of", t.shape[0])
