@@ -366,6 +366,41 @@ def test_float_incompressible_exponents(dg, ft, prob_bits):
         assert (tensor_to_words(ft, o) == w).all()
 
 
+def test_concurrent_streams(dg):
+    # Two streams compress and decompress different batches at the same time, repeatedly, without
+    # host synchronisation in between: per-call state (tickets, claim words, descriptors, spill
+    # slots) lives in each call's temp memory, the arrival counters are per stream, the parameter
+    # cache is shared.  Each encoder grid is sized for the whole chip, so the two kernels also
+    # run with only part of their workgroups resident.
+    rng = np.random.default_rng(77)
+    batches = []
+    for k in range(2):
+        ws = [refgen.generate_floats(O.BFLOAT16, 4096 * 8 * (12 + 5 * k) + 100 * i) for i in range(24)]
+        batches.append(ws)
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(2)]
+    results = [[], []]
+    for rep in range(4):
+        for k, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                ts = [words_to_tensor(O.BFLOAT16, w) for w in batches[k]]
+                comp, sizes, _ = dg.compress_data(True, ts, False, prob_bits=10)
+                outs = [torch.empty_like(t) for t in ts]
+                status = torch.zeros((len(ts),), dtype=torch.uint8, device=DEV)
+                arch = [comp[i] for i in range(len(ts))]
+                dg.decompress_data(True, arch, outs, False, None, status, None, prob_bits=10)
+                results[k].append((comp, sizes, outs, status))
+    torch.cuda.synchronize()
+    for k in range(2):
+        want = [O.float_compress(O.BFLOAT16, w, 10) for w in batches[k]]
+        for comp, sizes, outs, status in results[k]:
+            hs = sizes.cpu().numpy()
+            hc = comp.cpu().numpy()
+            assert status.cpu().numpy().all()
+            for i, w in enumerate(batches[k]):
+                assert hs[i] == want[i].size and (hc[i, : hs[i]] == want[i]).all(), (k, i)
+                assert (tensor_to_words(O.BFLOAT16, outs[i]) == w).all()
+
+
 @pytest.mark.parametrize("modulo", [2, 3, 7])
 def test_encoder_with_absent_workgroups(dg, modulo):
     # The encoder's static tile map must not depend on the whole grid being resident: with a
