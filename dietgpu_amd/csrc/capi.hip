@@ -384,6 +384,19 @@ uint32_t histPartsFor(uint32_t B, uint32_t maxBytes) {
   const uint32_t byBatch = divUp((uint32_t)DGPU_HIST_TARGET_WGS, std::max(B, 1u));
   return std::max(1u, std::min(std::min(bySize, byBatch), 256u));
 }
+// One or two large elements: the counts of an element's workgroups meet in 256 library-owned
+// atomic counters instead of per-workgroup partial histograms, so an element can be spread over
+// ~512 workgroups without the normalising workgroup having to sum 512 partial histograms (a single
+// 256 MiB tensor: 79 -> 52 us; more workgroups than that lose to contention on the counters).
+bool histAccumulates(uint32_t B, uint32_t maxBytes);
+uint32_t histPartsAccFor(uint32_t B, uint32_t maxBytes) {
+  const uint32_t bySize = divUp(std::max(maxBytes, 1u), 64u * 1024u);
+#ifndef DGPU_HIST_ACC_WGS
+#define DGPU_HIST_ACC_WGS 512
+#endif
+  const uint32_t byBatch = divUp((uint32_t)DGPU_HIST_ACC_WGS, std::max(B, 1u));
+  return std::max(1u, std::min(bySize, byBatch));
+}
 
 uint32_t gridX(uint32_t maxBytes, uint32_t bytesPerBlock, uint32_t cap) {
   uint32_t x = divUp(std::max(maxBytes, 1u), bytesPerBlock);
@@ -531,11 +544,19 @@ uint32_t tilesFor(uint32_t maxSize) { return divUp(divUp(maxSize, kBlockSize), k
 
 uint32_t absentWorkgroupModulo();  // test hook, defined with the C ABI below
 
+bool histAccumulates(uint32_t B, uint32_t maxBytes) {
+#ifndef DGPU_HIST_ACC_MAX_B
+#define DGPU_HIST_ACC_MAX_B 2
+#endif
+  return B <= (uint32_t)DGPU_HIST_ACC_MAX_B && histPartsAccFor(B, maxBytes) > histPartsFor(B, maxBytes);
+}
+
 // Library-owned arrival counters for the histogram -> normalisation hand-off
 // (HistFuse): 65536 u32 per (device, stream), zero at rest -- the kernel that uses
 // them puts them back to zero.  Keyed by stream because calls on one stream are
 // ordered while calls on different streams may overlap.
-int arrivalCounters(hipStream_t stream, uint32_t** out) {
+constexpr uint32_t kAccElements = 64;  // batches up to this size may use the accumulate-by-atomics histogram
+int arrivalCounters(hipStream_t stream, uint32_t** out, uint32_t** acc) {
   static std::mutex mu;
   static std::map<std::pair<int, hipStream_t>, uint32_t*> counters;
   std::lock_guard<std::mutex> g(mu);
@@ -545,11 +566,13 @@ int arrivalCounters(hipStream_t stream, uint32_t** out) {
   auto it = counters.find(key);
   if (it == counters.end()) {
     uint32_t* p = nullptr;
-    DGPU_HIP(hipMalloc((void**)&p, 65536 * sizeof(uint32_t)));
-    DGPU_HIP(hipMemset(p, 0, 65536 * sizeof(uint32_t)));  // once per (device, stream); synchronous
+    const size_t words = 65536 + (size_t)kAccElements * kNumSymbols;
+    DGPU_HIP(hipMalloc((void**)&p, words * sizeof(uint32_t)));
+    DGPU_HIP(hipMemset(p, 0, words * sizeof(uint32_t)));  // once per (device, stream); synchronous
     it = counters.emplace(key, p).first;
   }
   *out = it->second;
+  *acc = it->second + 65536;
   return DGPU_OK;
 }
 
@@ -587,6 +610,7 @@ int encodeCommon(
   NormalizeArgs n;
   n.sizes = in;
   n.hist = hist_dev;
+  n.histAcc = nullptr;
   n.histParts = 1;
   n.probBits = P;
   n.encTable = table;
@@ -606,12 +630,20 @@ int encodeCommon(
   n.numInBatch = B;
 
   if (!hist_dev) {
-    dim3 grid(histPartsFor(B, maxSize * wordBytes), B);
-    DGPU_ALLOC(histTemp, uint32_t, arena, (size_t)B * grid.x * kNumSymbols);
+    const bool accumulate = histAccumulates(B, maxSize * wordBytes);
+    dim3 grid(accumulate ? histPartsAccFor(B, maxSize * wordBytes) : histPartsFor(B, maxSize * wordBytes), B);
+    uint32_t* histTemp = nullptr;
+    if (!accumulate) {
+      DGPU_ALLOC(ht, uint32_t, arena, (size_t)B * grid.x * kNumSymbols);
+      histTemp = ht;
+    }
     HistFuse fuse;
-    int rc = arrivalCounters(stream, &fuse.arrive);
+    uint32_t* acc = nullptr;
+    int rc = arrivalCounters(stream, &fuse.arrive, &acc);
     if (rc) return rc;
+    fuse.acc = accumulate ? acc : nullptr;
     n.hist = histTemp;
+    n.histAcc = fuse.acc;
     n.histParts = grid.x;
     fuse.norm = n;
     switch (floatType) {
@@ -1249,6 +1281,7 @@ int dgpu_ans_histogram_batch_stride(
   dim3 grid(gridX(inPerBatchSize, 32 * 1024, 64), numInBatch);
   HistFuse noFuse;
   noFuse.arrive = nullptr;
+  noFuse.acc = nullptr;
   noFuse.norm = NormalizeArgs{};
   hipLaunchKernelGGL(k_histogram, grid, dim3(256), 0, (hipStream_t)stream, in, histogram_dev, 0u, noFuse);
   DGPU_HIP(hipGetLastError());
@@ -1263,6 +1296,7 @@ int dgpu_ans_calc_weights(
   NormalizeArgs n;
   n.sizes = viewPointers(nullptr, sizes_dev, uniformSize);
   n.hist = histogram_dev;
+  n.histAcc = nullptr;
   n.histParts = 1;
   n.probBits = probBits;
   n.encTable = nullptr;

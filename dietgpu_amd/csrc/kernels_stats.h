@@ -50,6 +50,8 @@ __device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v, uint32_t lane)
 struct NormalizeArgs {
   BatchView sizes;           // only size(b) is used
   const uint32_t* hist;      // [B][histParts][256]: per-workgroup partial histograms, summed here
+  uint32_t* histAcc;         // nullable: [B][256] counts accumulated by atomics (library-owned, zero at rest);
+                             // used instead of `hist`, read and put back to zero here
   uint32_t histParts;
   int probBits;
   uint4* encTable;           // [B][256] nullable
@@ -100,9 +102,14 @@ __device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const u
   }
 
   if (total != 0) {
-    // sum of the per-workgroup partial histograms, up to 16 loads in flight
     uint32_t count = 0;
-    {
+    if (a.histAcc) {
+      // counts accumulated with atomics by the histogram workgroups of this element
+      uint32_t* acc = a.histAcc + (size_t)b * kNumSymbols + tid;
+      count = __hip_atomic_load(acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(acc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero at rest
+    } else {
+      // sum of the per-workgroup partial histograms, up to 16 loads in flight
       const uint32_t* hp = a.hist + (size_t)b * a.histParts * kNumSymbols + tid;
       auto part = [&](uint32_t x) -> uint32_t {
         const uint32_t* q = hp + (size_t)x * kNumSymbols;
@@ -276,6 +283,7 @@ __global__ __launch_bounds__(256) void k_normalize(NormalizeArgs a) { normalizeE
 // workgroup resets it.  arrive == nullptr: plain histogram.
 struct HistFuse {
   uint32_t* arrive;  // [B], zero at launch
+  uint32_t* acc;     // nullable: [B][256] accumulate-by-atomics mode (few, large elements), zero at launch
   NormalizeArgs norm;
 };
 
@@ -342,7 +350,13 @@ __device__ __forceinline__ void histStore(uint32_t* __restrict__ hist, uint32_t 
     return;
   }
   __shared__ uint32_t sLast;
-  __hip_atomic_store(slot, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
+  if (f.acc) {
+    // few large elements: thousands of workgroups per element; their counts meet in
+    // 256 atomic counters instead of thousands of partial histograms
+    if (sum) __hip_atomic_fetch_add(f.acc + (size_t)b * kNumSymbols + tid, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    __hip_atomic_store(slot, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // ... and performed
   __syncthreads();
   if (tid == 0) {
