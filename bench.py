@@ -56,6 +56,10 @@ def make_workload(kind, batch, seed, device, n=512 * 1024):
         mask = torch.rand((batch, n), generator=g, device=device) < 0.5
         t = t.masked_fill(mask, 0.0).to(torch.float16)
         return t, 1, 2, 11, f"{batch}x{n} float16 N(0,1) 50% zeros, float codec, probBits 11 (BASELINE config 4)"
+    if kind == "fp32":
+        g = torch.Generator(device=device).manual_seed(seed)
+        t = torch.randn((batch, n // 2), generator=g, device=device, dtype=torch.float32)
+        return t, 3, 4, 10, f"{batch}x{n // 2} float32 N(0,1), float codec, probBits 10 (not a BASELINE config)"
     if kind == "u8":
         import refgen
 
@@ -237,7 +241,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="bf16", choices=["bf16", "u8", "fp16"])
+    ap.add_argument("--workload", default="bf16", choices=["bf16", "u8", "fp16", "fp32"])
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--elems", type=int, default=512 * 1024,
                     help="elements per tensor for the float workloads (default = BASELINE configs: 524288)")

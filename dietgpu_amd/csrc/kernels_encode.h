@@ -174,6 +174,7 @@ struct ChunkSource;
 
 template <>
 struct ChunkSource<0> {  // raw bytes: the symbols are the input
+  static constexpr uint32_t kRows = 16;  // rows per chunk
   struct Raw { uint4 v; };
   const uint8_t* in;  // this half's block
   __device__ __forceinline__ void init(const uint8_t* elemIn, uint8_t*, uint32_t, uint32_t block) {
@@ -184,7 +185,7 @@ struct ChunkSource<0> {  // raw bytes: the symbols are the input
     r.v = streamLoad<DGPU_NT_ENC_LOADS != 0>(&((const uint4*)in)[c * 32u + hl]);
     return r;
   }
-  __device__ __forceinline__ uint4 consume(const Raw& r, uint32_t, uint32_t) const { return r.v; }
+  __device__ __forceinline__ void consume(const Raw& r, uint32_t, uint32_t hl, uint8_t* ring) const { *(uint4*)(ring + hl * 16u) = r.v; }
   __device__ __forceinline__ uint32_t wordAt(uint32_t i) const { return in[i]; }
   __device__ __forceinline__ uint32_t splitAt(uint32_t, uint32_t w, bool) const { return w; }
 };
@@ -197,6 +198,7 @@ __device__ __forceinline__ uint32_t bitSelect(uint32_t mask, uint32_t a, uint32_
 
 template <uint32_t FT>  // kFloat16 / kBFloat16: 2-byte words, 1 comp byte + 1 non-comp byte
 struct ChunkSource16 {
+  static constexpr uint32_t kRows = 16;
   struct Raw { uint4 a, b; };
   const uint16_t* in;  // this half's block (4096 words)
   uint8_t* nc;         // this half's block of the non-comp plane
@@ -212,7 +214,7 @@ struct ChunkSource16 {
     return r;
   }
   // FloatTypeInfo<FT>::split (GpuFloatUtils.cuh:111-115, 141-147) on packed pairs
-  __device__ __forceinline__ uint4 consume(const Raw& r, uint32_t c, uint32_t hl) const {
+  __device__ __forceinline__ void consume(const Raw& r, uint32_t c, uint32_t hl, uint8_t* ring) const {
     const uint32_t x[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w};
     uint32_t comp[4], rest[4];
     if (FT == kFloat16) {
@@ -242,7 +244,7 @@ struct ChunkSource16 {
       }
     }
     streamStore<DGPU_NT_ENC_STORES != 0>(&((uint4*)(nc + c * 512u))[hl], make_uint4(rest[0], rest[1], rest[2], rest[3]));
-    return make_uint4(comp[0], comp[1], comp[2], comp[3]);
+    *(uint4*)(ring + hl * 16u) = make_uint4(comp[0], comp[1], comp[2], comp[3]);
   }
   __device__ __forceinline__ uint32_t wordAt(uint32_t i) const { return in[i]; }
   __device__ __forceinline__ uint32_t splitAt(uint32_t i, uint32_t w, bool valid) const {
@@ -265,7 +267,10 @@ struct ChunkSource<kBFloat16> : ChunkSource16<kBFloat16> {};
 
 template <>
 struct ChunkSource<kFloat32> {  // 4-byte words: comp byte + 24 non-comp bits (u16 plane, then u8 plane)
-  struct Raw { uint4 v[4]; };
+  // 8-row chunks (256 symbols, 8 words = 32 bytes per lane): a 16-row chunk in
+  // flight is 16 registers, which the row loop cannot afford (it spilled)
+  static constexpr uint32_t kRows = 8;
+  struct Raw { uint4 v[2]; };
   const uint32_t* in;
   uint16_t* nc2;
   uint8_t* nc1;
@@ -275,25 +280,25 @@ struct ChunkSource<kFloat32> {  // 4-byte words: comp byte + 24 non-comp bits (u
     nc1 = archive + 16u + 2u * (size_t)roundUp(size, 8u) + (size_t)block * kBlockSize;
   }
   __device__ __forceinline__ Raw load(uint32_t c, uint32_t hl) const {
-    const uint4* p = (const uint4*)(in + c * 512u + hl * 16u);
+    const uint4* p = (const uint4*)(in + c * 256u + hl * 8u);
     Raw r;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) r.v[j] = streamLoad<DGPU_NT_ENC_LOADS != 0>(&p[j]);
+    r.v[0] = streamLoad<DGPU_NT_ENC_LOADS != 0>(&p[0]);
+    r.v[1] = streamLoad<DGPU_NT_ENC_LOADS != 0>(&p[1]);
     return r;
   }
   // FloatTypeInfo<kFloat32>::split (GpuFloatUtils.cuh:181-185): v = rotl(w, 1)
-  __device__ __forceinline__ uint4 consume(const Raw& r, uint32_t c, uint32_t hl) const {
-    uint32_t v[16];
+  __device__ __forceinline__ void consume(const Raw& r, uint32_t c, uint32_t hl, uint8_t* ring) const {
+    uint32_t v[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 2; ++j) {
       v[4 * j + 0] = __builtin_amdgcn_alignbit(r.v[j].x, r.v[j].x, 31);
       v[4 * j + 1] = __builtin_amdgcn_alignbit(r.v[j].y, r.v[j].y, 31);
       v[4 * j + 2] = __builtin_amdgcn_alignbit(r.v[j].z, r.v[j].z, 31);
       v[4 * j + 3] = __builtin_amdgcn_alignbit(r.v[j].w, r.v[j].w, 31);
     }
-    uint32_t comp[4], hi[4], lo[8];
+    uint32_t comp[2], hi[2], lo[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 2; ++j) {
       // bytes 2 (high non-comp byte) and 3 (comp) of four words -> one dword each
       const uint32_t a = __builtin_amdgcn_perm(v[4 * j + 1], v[4 * j + 0], 0x07030602u);  // {v0.b2, v1.b2, v0.b3, v1.b3}
       const uint32_t b = __builtin_amdgcn_perm(v[4 * j + 3], v[4 * j + 2], 0x07030602u);
@@ -302,11 +307,9 @@ struct ChunkSource<kFloat32> {  // 4-byte words: comp byte + 24 non-comp bits (u
       lo[2 * j + 0] = __builtin_amdgcn_perm(v[4 * j + 1], v[4 * j + 0], 0x05040100u);  // low 16 bits of two words
       lo[2 * j + 1] = __builtin_amdgcn_perm(v[4 * j + 3], v[4 * j + 2], 0x05040100u);
     }
-    uint4* p2 = (uint4*)(nc2 + c * 512u + hl * 16u);
-    streamStore<DGPU_NT_ENC_STORES != 0>(&p2[0], make_uint4(lo[0], lo[1], lo[2], lo[3]));
-    streamStore<DGPU_NT_ENC_STORES != 0>(&p2[1], make_uint4(lo[4], lo[5], lo[6], lo[7]));
-    streamStore<DGPU_NT_ENC_STORES != 0>(&((uint4*)(nc1 + c * 512u))[hl], make_uint4(hi[0], hi[1], hi[2], hi[3]));
-    return make_uint4(comp[0], comp[1], comp[2], comp[3]);
+    streamStore<DGPU_NT_ENC_STORES != 0>((uint4*)(nc2 + c * 256u + hl * 8u), make_uint4(lo[0], lo[1], lo[2], lo[3]));
+    *(uint2*)(nc1 + c * 256u + hl * 8u) = make_uint2(hi[0], hi[1]);
+    *(uint2*)(ring + hl * 8u) = make_uint2(comp[0], comp[1]);
   }
   __device__ __forceinline__ uint32_t wordAt(uint32_t i) const { return in[i]; }
   __device__ __forceinline__ uint32_t splitAt(uint32_t i, uint32_t w, bool valid) const {
@@ -425,7 +428,7 @@ __device__ __forceinline__ uint32_t encodeRows(
     outOff += __popc(vh);
   };
   if (kFull) {
-    // 8 chunks of 16 rows; chunk c+1 is in flight in registers while chunk c is
+    // chunks of 16 rows (8 for fp32); chunk c+1 is in flight in registers while chunk c is
     // consumed from the LDS ring (same wave writes and reads it: LDS ops of one
     // wave execute in order, no barrier needed).
     // table entries in flight ahead of the row being encoded (measured: 2 beats 4 --
@@ -434,12 +437,12 @@ __device__ __forceinline__ uint32_t encodeRows(
 #define DGPU_ENC_AHEAD 2
 #endif
     constexpr int kAhead = DGPU_ENC_AHEAD;
+    constexpr uint32_t kChunkRows = ChunkSource<FT>::kRows;
     typename ChunkSource<FT>::Raw cur = src.load(0, hl);
 #pragma unroll 1
-    for (uint32_t c = 0; c < kRowsPerBlock / 16; ++c) {
-      const uint4 symbols = src.consume(cur, c, hl);
-      *(uint4*)(ring + hl * 16u) = symbols;
-      if (c + 1 < kRowsPerBlock / 16) cur = src.load(c + 1, hl);
+    for (uint32_t c = 0; c < kRowsPerBlock / kChunkRows; ++c) {
+      src.consume(cur, c, hl, ring);
+      if (c + 1 < kRowsPerBlock / kChunkRows) cur = src.load(c + 1, hl);
       // LDS addresses of the table entries (table + sym * 16), formed right at the
       // symbol load; kSymAhead symbols and kAhead table entries are in flight.
       // (Reading all 16 symbols of the chunk up front costs 16 live registers.)
@@ -447,7 +450,7 @@ __device__ __forceinline__ uint32_t encodeRows(
 #define DGPU_ENC_SYM_AHEAD 4
 #endif
       constexpr int kSymAhead = DGPU_ENC_SYM_AHEAD;
-      static_assert(kSymAhead > kAhead && kSymAhead <= 16, "a symbol slot is reused only after its table load was issued");
+      static_assert(kSymAhead > kAhead && kSymAhead <= (int)kChunkRows, "a symbol slot is reused only after its table load was issued");
       auto symAddr = [&](int r) -> uint32_t {
         uint32_t t = tableLds + ((uint32_t)ring[r * 32 + hl] << 4);
         asm volatile("" : "+v"(t));  // keep the scaled address; do not re-derive it (with a mask) at the use
@@ -460,11 +463,11 @@ __device__ __forceinline__ uint32_t encodeRows(
 #pragma unroll
       for (int r = 0; r < kAhead; ++r) e[r] = ldsTableEntry(toff[r]);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < (int)kChunkRows; ++r) {
         if (r % kFlushRows == 0) makeRoom();
         const uint4 cur_e = e[r % kAhead];
-        if (r + kAhead < 16) e[r % kAhead] = ldsTableEntry(toff[(r + kAhead) % kSymAhead]);
-        if (r + kSymAhead < 16) toff[r % kSymAhead] = symAddr(r + kSymAhead);
+        if (r + kAhead < (int)kChunkRows) e[r % kAhead] = ldsTableEntry(toff[(r + kAhead) % kSymAhead]);
+        if (r + kSymAhead < (int)kChunkRows) toff[r % kSymAhead] = symAddr(r + kSymAhead);
 #if DGPU_ENC_ASM_STEP
         stepFullAsm(cur_e);
 #else
