@@ -100,6 +100,58 @@ class KernelTimer {
 // ---------------------------------------------------------------------------
 // Temp memory: bump allocation out of the caller's region; if it does not fit,
 // fall back to hipMalloc with a warning (StackDeviceMemory.cpp:119-139).
+// Library-owned overflow memory, one grow-only slab per (device, stream).  When
+// the caller's temp memory is missing or too small the reference falls back to
+// cudaMalloc + cudaFree around every call (synchronising).  Here the overflow
+// comes from a slab that is kept between calls: calls on one stream execute in
+// order, so the slab can be re-used from offset 0 by every call without any
+// synchronisation.  A slab that has to grow is retired (freed after a stream
+// synchronise at the next growth), never freed under kernels that may use it.
+class OverflowPool {
+ public:
+  struct Slab {
+    uint8_t* base = nullptr;
+    size_t cap = 0;
+    std::vector<void*> retired;
+  };
+  // Returns memory for [head, head + need) of this stream's slab, growing it if necessary;
+  // *head is advanced.  A grown slab restarts at offset 0 (earlier pointers stay valid: retired).
+  void* take(hipStream_t stream, size_t* head, size_t need, hipError_t* err) {
+    std::lock_guard<std::mutex> g(mu_);
+    int dev = 0;
+    *err = hipGetDevice(&dev);
+    if (*err != hipSuccess) return nullptr;
+    Slab& s = slabs_[std::make_pair(dev, stream)];
+    if (*head + need > s.cap) {
+      if (!s.retired.empty()) {
+        (void)hipStreamSynchronize(stream);
+        for (void* p : s.retired) (void)hipFree(p);
+        s.retired.clear();
+      }
+      const size_t cap = std::max<size_t>(std::max(2 * s.cap, need + (need >> 2)), (size_t)8 << 20);
+      void* p = nullptr;
+      *err = hipMalloc(&p, cap);
+      if (*err != hipSuccess) return nullptr;
+      if (s.base) s.retired.push_back(s.base);
+      s.base = (uint8_t*)p;
+      s.cap = cap;
+      *head = 0;
+    }
+    void* out = s.base + *head;
+    *head += need;
+    return out;
+  }
+
+ private:
+  std::mutex mu_;
+  std::map<std::pair<int, hipStream_t>, Slab> slabs_;
+};
+
+OverflowPool& overflowPool() {
+  static OverflowPool* p = new OverflowPool();  // intentionally leaked: no teardown-order issues
+  return *p;
+}
+
 class TempArena {
  public:
   TempArena(void* base, size_t bytes, hipStream_t stream)
@@ -117,7 +169,6 @@ class TempArena {
       }
     }
   }
-  ~TempArena() { release(); }
 
   template <typename T>
   T* alloc(size_t count, hipError_t* err) {
@@ -128,42 +179,27 @@ class TempArena {
       head_ += need;
       return p;
     }
-    void* p = nullptr;
-    hipError_t e = hipMalloc(&p, need);
-    if (e != hipSuccess) {
-      *err = e;
-      return nullptr;
-    }
     // no warning when the caller chose to pass no temp memory at all
     if (!warned_ && bytes_ > 0) {
       fprintf(stderr,
               "dietgpu_amd: WARNING: temp memory too small (%zu bytes given, > %zu needed); "
-              "falling back to hipMalloc, which synchronises\n",
+              "using library-owned overflow memory\n",
               bytes_, requested_);
       warned_ = true;
     }
-    overflow_.push_back(p);
-    return (T*)p;
+    return (T*)overflowPool().take(stream_, &overflowHead_, need, err);
   }
 
   size_t requested() const { return requested_; }
-
-  void release() {
-    if (!overflow_.empty()) {
-      (void)hipStreamSynchronize(stream_);
-      for (void* p : overflow_) (void)hipFree(p);
-      overflow_.clear();
-    }
-  }
 
  private:
   uint8_t* base_;
   size_t bytes_;
   hipStream_t stream_;
   size_t head_ = 0;
+  size_t overflowHead_ = 0;
   size_t requested_ = 0;
   bool warned_ = false;
-  std::vector<void*> overflow_;
 };
 
 #define DGPU_ALLOC(var, T, arena, count)                                     \
