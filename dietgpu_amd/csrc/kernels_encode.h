@@ -55,9 +55,6 @@
 #define DGPU_SCHEDULE 2
 #endif
 #define DGPU_STATIC_SCHEDULE (DGPU_SCHEDULE == 1)
-#ifndef DGPU_ENC_ASM_STEP
-#define DGPU_ENC_ASM_STEP 0
-#endif
 
 namespace dgpu {
 
@@ -387,34 +384,8 @@ __device__ __forceinline__ uint32_t encodeRows(
   };
 
   // Full-block step: straight-line code, no exec-mask change and no branch.
-  // The front half is hand-scheduled: the compiler does not form the SDWA select
-  // (renormalised state = state.WORD_1 where the lane emits) and would need an
-  // s_nop between the compare and the use of vcc as shift data.
-  //   write = state >= e.x;  vh = this half's 32 ballot bits
-  //   sel   = write ? state >> 16 : state;  t = umulhi(sel, e.y)
-  //   addr  = write ? stageBase + 2 * (outOff + popc(vh & lanesBelow)) : dummyAddr
-  const uint32_t halfShift = upper ? 32u : 0u;
-  auto stepFullAsm = [&](const uint4 e) {
-    uint32_t sel, t, addr;
-    uint64_t vh64;
-    asm("v_cmp_ge_u32 vcc, %[st], %[ex]\n\t"
-        "v_cndmask_b32_sdwa %[sel], %[st], %[st], vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
-        "v_mul_hi_u32 %[t], %[sel], %[ey]\n\t"
-        "v_lshrrev_b64 v[78:79], %[hs], vcc\n\t"
-        "v_and_b32 %[addr], v78, %[lt]\n\t"
-        "v_bcnt_u32_b32 %[addr], %[addr], %[off]\n\t"
-        "v_lshl_add_u32 %[addr], %[addr], 1, %[sb]\n\t"
-        "v_cndmask_b32 %[addr], %[dm], %[addr], vcc"
-        : [sel] "=&v"(sel), [t] "=&v"(t), "=&{v[78:79]}"(vh64), [addr] "=&v"(addr)
-        : [st] "v"(state), [ex] "v"(e.x), [ey] "v"(e.y), [hs] "v"(halfShift), [lt] "v"(laneMaskLt),
-          [off] "v"(outOff), [sb] "v"(stageBase), [dm] "v"(dummyAddr)
-        : "vcc");
-    *(LdsU16e*)(uintptr_t)addr = (uint16_t)state;
-    const uint32_t div = t >> (e.w >> 24);
-    state = __umul24(div, e.w) + sel + e.z;
-    outOff += __popc((uint32_t)vh64);
-  };
-
+  // (A hand-scheduled variant of this step with an SDWA select -- two instructions
+  // shorter -- measured 5 % slower: see DESIGN.md section 4.1.)
   auto stepFullC = [&](const uint4 e) {
     const bool write = state >= e.x;
     const uint64_t vote = __ballot(write);
@@ -468,11 +439,7 @@ __device__ __forceinline__ uint32_t encodeRows(
         const uint4 cur_e = e[r % kAhead];
         if (r + kAhead < (int)kChunkRows) e[r % kAhead] = ldsTableEntry(toff[(r + kAhead) % kSymAhead]);
         if (r + kSymAhead < (int)kChunkRows) toff[r % kSymAhead] = symAddr(r + kSymAhead);
-#if DGPU_ENC_ASM_STEP
-        stepFullAsm(cur_e);
-#else
         stepFullC(cur_e);
-#endif
       }
     }
   } else {
