@@ -366,6 +366,66 @@ def test_float_incompressible_exponents(dg, ft, prob_bits):
         assert (tensor_to_words(ft, o) == w).all()
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_ragged_batches(dg, seed):
+    # random ragged batches: element sizes from empty to ~60 blocks (so that elements span 0..8
+    # encoder tiles and both decoder workgroup shapes), random type / probBits / checksum,
+    # compressible and incompressible elements mixed; archives byte-identical to the oracle,
+    # decode bit-exact, reported sizes exact
+    rng = np.random.default_rng(9000 + seed)
+    for trial in range(5):
+        ft = int(rng.choice([0, O.FLOAT16, O.BFLOAT16, O.FLOAT32]))
+        P = int(rng.choice([9, 10, 11]))
+        cksum = bool(rng.integers(0, 2))
+        B = int(rng.integers(1, 40))
+        ns = []
+        for _ in range(B):
+            kind = rng.integers(0, 10)
+            if kind == 0:
+                ns.append(0)
+            elif kind < 4:
+                ns.append(int(rng.integers(1, 5000)))
+            else:
+                ns.append(int(rng.integers(1, 60)) * 4096 + int(rng.integers(0, 2)) * int(rng.integers(0, 4096)))
+        if ft == 0:
+            xs = []
+            for n in ns:
+                lam = float(rng.choice([2.0, 30.0, 300.0]))
+                x = refgen.generate_symbols(max(n, 1), lam)[:n] if rng.integers(0, 4) else rng.integers(0, 256, n, dtype=np.uint8)
+                xs.append(np.ascontiguousarray(x, np.uint8))
+            got = gpu_ans_encode(dg, [x if x.size else np.zeros(0, np.uint8) for x in xs], P, cksum)
+            for i, x in enumerate(xs):
+                want = O.ans_encode(x, P, use_checksum=cksum)
+                assert got[i].size == want.size and (got[i] == want).all(), (seed, trial, "raw", i, x.size)
+            outs, status, osz = gpu_ans_decode(dg, got, [x.size for x in xs], P, cksum)
+            assert status.all() and osz.tolist() == [x.size for x in xs]
+            for x, o in zip(xs, outs):
+                assert (o == x).all()
+        else:
+            dt = np.uint32 if ft == O.FLOAT32 else np.uint16
+            hi = 1 << (32 if ft == O.FLOAT32 else 16)
+            ws = []
+            for n in ns:
+                w = refgen.generate_floats(ft, max(n, 1))[:n] if rng.integers(0, 4) else rng.integers(0, hi, n, dtype=np.uint64).astype(dt)
+                ws.append(np.ascontiguousarray(w, dt))
+            ts = [words_to_tensor(ft, w) for w in ws]
+            comp, sizes, _ = dg.compress_data(True, ts, cksum, prob_bits=P)
+            hs = sizes.cpu().numpy()
+            hc = comp.cpu().numpy()
+            arch = []
+            for i, w in enumerate(ws):
+                want = O.float_compress(ft, w, P, use_checksum=cksum)
+                assert hs[i] == want.size and (hc[i, : hs[i]] == want).all(), (seed, trial, ft, P, i, w.size)
+                arch.append(comp[i, : hs[i]].clone())
+            outs = [torch.empty_like(t) for t in ts]
+            status = torch.zeros((B,), dtype=torch.uint8, device=DEV)
+            osz = torch.zeros((B,), dtype=torch.int32, device=DEV)
+            dg.decompress_data(True, arch, outs, cksum, None, status, osz, prob_bits=P)
+            assert status.cpu().numpy().all() and osz.cpu().tolist() == ns
+            for w, o in zip(ws, outs):
+                assert (tensor_to_words(ft, o) == w).all()
+
+
 def test_concurrent_streams(dg):
     # Two streams compress and decompress different batches at the same time, repeatedly, without
     # host synchronisation in between: per-call state (tickets, claim words, descriptors, spill
