@@ -519,7 +519,7 @@ uint32_t encodeGridPF(uint32_t tickets) {
   static const uint32_t perCu = [] {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &n, (k_ans_encode<P, FT, encodeSpills(FT)>), 256, encLdsBytes(P, encodeSpills(FT))) != hipSuccess || n < 1) {
+            &n, (k_ans_encode<P, FT, encodeSpills(FT)>), 256, encLdsBytes(P, encodeSpills(FT), FT)) != hipSuccess || n < 1) {
       n = 1;
     }
     return (uint32_t)n;
@@ -535,7 +535,7 @@ uint32_t encodeGridPF(uint32_t tickets) {
 template <int P, uint32_t FT>
 int launchEncodePF(const EncodeArgs& a, uint32_t grid, hipStream_t stream) {
   constexpr bool kSpill = encodeSpills(FT);
-  DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT, kSpill>), dim3(grid), dim3(256), encLdsBytes(P, kSpill), stream, a);
+  DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT, kSpill>), dim3(grid), dim3(256), encLdsBytes(P, kSpill, FT), stream, a);
   DGPU_HIP(hipGetLastError());
   return DGPU_OK;
 }
@@ -1014,7 +1014,7 @@ static size_t encodeTempBytes(uint32_t B, uint32_t maxBytes, uint32_t wordBytes,
   t += alignUp((size_t)B * tiles * 4, kTempAlign);                                // tile claim words
   if (spills) {
     // spill slots of the persistent encoder workgroups (bounded by what fits on the chip)
-    size_t perCu = (160u * 1024u) / encLdsBytes(9, true);
+    size_t perCu = (160u * 1024u) / encLdsBytes(9, true, kBFloat16);
     size_t grid = std::min((size_t)B * tiles, perCu * numComputeUnits());
     t += alignUp(grid * kBlocksPerTile * encSpillSlotWords(11) * 2, kTempAlign);
   }

@@ -75,18 +75,22 @@ __host__ __device__ constexpr uint32_t encStageWords(int P) { return 32u * (8u *
 //     look-back / copy-out phases.  Exponent streams (2-4 bits per symbol) never
 //     reach the flush threshold of 3 bits/symbol averaged over a block; the
 //     spill path is the safety net for incompressible inputs, not the fast path.
-constexpr uint32_t kSpillStageWords = 1024;
+constexpr uint32_t kSpillStageWords = 1024;       // bf16 / fp32: the compressed byte is the 8-bit exponent
+// fp16's compressed byte is sign + 5 exponent bits + 2 MANTISSA bits: ~2 bits more entropy.  With
+// 1024 words most blocks of BASELINE config 4 flushed (encode 107 us, and the spill traffic pushed
+// the archive out of the memory-side cache: decode 122 us); 1280 words (5 workgroups per CU): 91 / 104.
+constexpr uint32_t kSpillStageWordsFp16 = 1280;
 constexpr uint32_t kFlushRows = 8;
 // words of spill slot per block: the worst case of a block (whole vectors)
 __host__ __device__ constexpr uint32_t encSpillSlotWords(int P) { return roundUp(encStageWords(P), 8u) + 8u; }
 
-__host__ __device__ constexpr uint32_t encStageCap(int P, bool spill) {
-  return spill ? kSpillStageWords : encStageWords(P);
+__host__ __device__ constexpr uint32_t encStageCap(int P, bool spill, uint32_t ft) {
+  return spill ? (ft == kFloat16 ? kSpillStageWordsFp16 : kSpillStageWords) : encStageWords(P);
 }
-__host__ __device__ constexpr uint32_t encLdsBytes(int P, bool spill) {
+__host__ __device__ constexpr uint32_t encLdsBytes(int P, bool spill, uint32_t ft) {
   return 4096u                                       // packed symbol table
       + 128u                                         // tile bookkeeping
-      + kBlocksPerTile * encStageCap(P, spill) * 2u  // bitstream stage per half-wave
+      + kBlocksPerTile * encStageCap(P, spill, ft) * 2u  // bitstream stage per half-wave
       + kBlocksPerTile * 512u                        // symbol ring, 16 rows per half-wave
       + 512u;                                        // scratch slots of non-emitting lanes
 }
@@ -345,7 +349,7 @@ __device__ __forceinline__ uint32_t encodeRows(
     if (!kSpill) return;
     const uint32_t o0 = __builtin_amdgcn_readlane(outOff, 0);
     const uint32_t o1 = __builtin_amdgcn_readlane(outOff, 32);
-    if ((o0 > o1 ? o0 : o1) + kFlushRows * 32u <= kSpillStageWords) return;  // wave-uniform
+    if ((o0 > o1 ? o0 : o1) + kFlushRows * 32u <= encStageCap(P, true, FT)) return;  // wave-uniform
     // whole 16-byte vectors go to the spill slot, the (< 8 word) rest moves to the front
     uint32_t nvec = outOff >> 3;
     // cannot happen with a table made from this data's histogram; keeps a
@@ -484,7 +488,7 @@ __device__ __forceinline__ uint32_t encodeRows(
 template <int P, uint32_t FT, bool kSpill>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_ans_encode(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  constexpr uint32_t kCap = encStageCap(P, kSpill);
+  constexpr uint32_t kCap = encStageCap(P, kSpill, FT);
   // bookkeeping sits BELOW the stages so that a stage overrun (only possible
   // without spilling, with a caller-supplied histogram that does not match the
   // data) can never reach it
