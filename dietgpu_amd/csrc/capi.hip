@@ -514,12 +514,12 @@ uint32_t numComputeUnits() {
 #endif
 constexpr bool encodeSpills(uint32_t ft) { return ft != 0 || DGPU_RAW_SPILLS; }
 
-template <int P, uint32_t FT>
-uint32_t encodeGridPF(uint32_t tickets) {
+template <int P, uint32_t FT, uint32_t TB>
+uint32_t encodeGridPFT(uint32_t tickets) {
   static const uint32_t perCu = [] {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &n, (k_ans_encode<P, FT, encodeSpills(FT)>), 256, encLdsBytes(P, encodeSpills(FT), FT)) != hipSuccess || n < 1) {
+            &n, (k_ans_encode<P, FT, encodeSpills(FT), TB>), TB * 32, encLdsBytes(P, encodeSpills(FT), FT, TB)) != hipSuccess || n < 1) {
       n = 1;
     }
     return (uint32_t)n;
@@ -531,11 +531,22 @@ uint32_t encodeGridPF(uint32_t tickets) {
   const uint32_t use = knob ? std::min(knob, perCu) : perCu;
   return std::max(1u, std::min(tickets, use * numComputeUnits()));
 }
+template <int P, uint32_t FT>
+uint32_t encodeGridPF(uint32_t tickets, uint32_t tileBlocks) {
+  return tileBlocks == kBlocksPerSmallTile ? encodeGridPFT<P, FT, kBlocksPerSmallTile>(tickets)
+                                           : encodeGridPFT<P, FT, kBlocksPerTile>(tickets);
+}
 
 template <int P, uint32_t FT>
-int launchEncodePF(const EncodeArgs& a, uint32_t grid, hipStream_t stream) {
+int launchEncodePF(const EncodeArgs& a, uint32_t tileBlocks, uint32_t grid, hipStream_t stream) {
   constexpr bool kSpill = encodeSpills(FT);
-  DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT, kSpill>), dim3(grid), dim3(256), encLdsBytes(P, kSpill, FT), stream, a);
+  if (tileBlocks == kBlocksPerSmallTile) {
+    DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT, kSpill, kBlocksPerSmallTile>), dim3(grid), dim3(kBlocksPerSmallTile * 32),
+                encLdsBytes(P, kSpill, FT, kBlocksPerSmallTile), stream, a);
+  } else {
+    DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT, kSpill, kBlocksPerTile>), dim3(grid), dim3(kBlocksPerTile * 32),
+                encLdsBytes(P, kSpill, FT, kBlocksPerTile), stream, a);
+  }
   DGPU_HIP(hipGetLastError());
   return DGPU_OK;
 }
@@ -564,19 +575,23 @@ int launchEncodePF(const EncodeArgs& a, uint32_t grid, hipStream_t stream) {
       break;                                                                  \
   }
 
-uint32_t encodeGrid(int P, uint32_t ft, uint32_t tickets) {
+uint32_t encodeGrid(int P, uint32_t ft, uint32_t tileBlocks, uint32_t tickets) {
   uint32_t g = 1;
-  DGPU_ENCODE_DISPATCH(P, ft, g = (encodeGridPF<kP, kFT>(tickets)));
+  DGPU_ENCODE_DISPATCH(P, ft, g = (encodeGridPF<kP, kFT>(tickets, tileBlocks)));
   return g;
 }
 
-int launchEncode(int P, uint32_t ft, const EncodeArgs& a, uint32_t grid, hipStream_t stream) {
+int launchEncode(int P, uint32_t ft, const EncodeArgs& a, uint32_t tileBlocks, uint32_t grid, hipStream_t stream) {
   int rc = DGPU_OK;
-  DGPU_ENCODE_DISPATCH(P, ft, rc = (launchEncodePF<kP, kFT>(a, grid, stream)));
+  DGPU_ENCODE_DISPATCH(P, ft, rc = (launchEncodePF<kP, kFT>(a, tileBlocks, grid, stream)));
   return rc;
 }
 
-uint32_t tilesFor(uint32_t maxSize) { return divUp(divUp(maxSize, kBlockSize), kBlocksPerTile); }
+// blocks per encoder tile for a batch whose largest element has `maxSize` symbols
+uint32_t encTileBlocksFor(uint32_t maxSize) {
+  return divUp(maxSize, kBlockSize) <= kBlocksPerSmallTile ? kBlocksPerSmallTile : kBlocksPerTile;
+}
+uint32_t tilesFor(uint32_t maxSize) { return divUp(divUp(maxSize, kBlockSize), encTileBlocksFor(maxSize)); }
 
 uint32_t absentWorkgroupModulo();  // test hook, defined with the C ABI below
 
@@ -682,20 +697,29 @@ int encodeCommon(
     n.histAcc = fuse.acc;
     n.histParts = grid.x;
     fuse.norm = n;
-    switch (floatType) {
-      case 0:
-        DGPU_LAUNCH("k_histogram", stream, k_histogram, grid, dim3(256), 0, stream, in, histTemp, 1u, fuse);
-        break;
-      case kFloat16:
-        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kFloat16>), grid, dim3(256), 0, stream, in, histTemp, 1u, fuse);
-        break;
-      case kBFloat16:
-        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kBFloat16>), grid, dim3(256), 0, stream, in, histTemp, 1u, fuse);
-        break;
-      default:
-        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kFloat32>), grid, dim3(256), 0, stream, in, histTemp, 1u, fuse);
-        break;
+    // bins with 32 lane slots unless a workgroup sees too little data to pay for zeroing / folding them
+    const bool smallBins = (uint64_t)maxSize * wordBytes / grid.x <= 64u * 1024u;
+#define DGPU_HIST_LAUNCH(S)                                                                                       \
+    switch (floatType) {                                                                                          \
+      case 0:                                                                                                     \
+        DGPU_LAUNCH("k_histogram", stream, (k_histogram<S>), grid, dim3(256), 0, stream, in, histTemp, 1u, fuse); \
+        break;                                                                                                    \
+      case kFloat16:                                                                                              \
+        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kFloat16, S>), grid, dim3(256), 0, stream, in, histTemp, 1u, fuse); \
+        break;                                                                                                    \
+      case kBFloat16:                                                                                             \
+        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kBFloat16, S>), grid, dim3(256), 0, stream, in, histTemp, 1u, fuse); \
+        break;                                                                                                    \
+      default:                                                                                                    \
+        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kFloat32, S>), grid, dim3(256), 0, stream, in, histTemp, 1u, fuse); \
+        break;                                                                                                    \
     }
+    if (smallBins) {
+      DGPU_HIST_LAUNCH(kHistSlotsSmall)
+    } else {
+      DGPU_HIST_LAUNCH(kHistSlotsLarge)
+    }
+#undef DGPU_HIST_LAUNCH
     DGPU_HIP(hipGetLastError());
   } else {
     // caller-supplied histogram: stand-alone normalisation
@@ -703,10 +727,11 @@ int encodeCommon(
     DGPU_HIP(hipGetLastError());
   }
   if (maxTiles > 0) {
-    const uint32_t grid = encodeGrid(P, floatType, B * maxTiles);
+    const uint32_t tileBlocks = encTileBlocksFor(maxSize);
+    const uint32_t grid = encodeGrid(P, floatType, tileBlocks, B * maxTiles);
     uint16_t* spill = nullptr;
     if (encodeSpills(floatType)) {
-      DGPU_ALLOC(sp, uint16_t, arena, (size_t)grid * kBlocksPerTile * encSpillSlotWords(P));
+      DGPU_ALLOC(sp, uint16_t, arena, (size_t)grid * tileBlocks * encSpillSlotWords(P));
       spill = sp;
     }
     EncodeArgs e;
@@ -724,7 +749,7 @@ int encodeCommon(
     e.outSize = outSize_dev;
     e.useChecksum = (useChecksum && floatType) ? 1 : 0;
     e.checksum = (useChecksum && floatType) ? checksumTemp : nullptr;
-    int rc = launchEncode(P, floatType, e, grid, stream);
+    int rc = launchEncode(P, floatType, e, tileBlocks, grid, stream);
     if (rc) return rc;
   }
   return DGPU_OK;
@@ -1014,7 +1039,7 @@ static size_t encodeTempBytes(uint32_t B, uint32_t maxBytes, uint32_t wordBytes,
   t += alignUp((size_t)B * tiles * 4, kTempAlign);                                // tile claim words
   if (spills) {
     // spill slots of the persistent encoder workgroups (bounded by what fits on the chip)
-    size_t perCu = (160u * 1024u) / encLdsBytes(9, true, kBFloat16);
+    size_t perCu = (160u * 1024u) / encLdsBytes(9, true, kBFloat16, kBlocksPerTile);
     size_t grid = std::min((size_t)B * tiles, perCu * numComputeUnits());
     t += alignUp(grid * kBlocksPerTile * encSpillSlotWords(11) * 2, kTempAlign);
   }
@@ -1319,7 +1344,7 @@ int dgpu_ans_histogram_batch_stride(
   noFuse.arrive = nullptr;
   noFuse.acc = nullptr;
   noFuse.norm = NormalizeArgs{};
-  hipLaunchKernelGGL(k_histogram, grid, dim3(256), 0, (hipStream_t)stream, in, histogram_dev, 0u, noFuse);
+  hipLaunchKernelGGL((k_histogram<kHistSlotsLarge>), grid, dim3(256), 0, (hipStream_t)stream, in, histogram_dev, 0u, noFuse);
   DGPU_HIP(hipGetLastError());
   return DGPU_OK;
 }

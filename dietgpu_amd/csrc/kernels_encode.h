@@ -87,11 +87,14 @@ __host__ __device__ constexpr uint32_t encSpillSlotWords(int P) { return roundUp
 __host__ __device__ constexpr uint32_t encStageCap(int P, bool spill, uint32_t ft) {
   return spill ? (ft == kFloat16 ? kSpillStageWordsFp16 : kSpillStageWords) : encStageWords(P);
 }
-__host__ __device__ constexpr uint32_t encLdsBytes(int P, bool spill, uint32_t ft) {
+// Blocks per tile = per workgroup: 8 (256 threads), or 4 (128 threads) for batches whose elements have
+// at most 4 blocks -- an 8-block tile would leave half of its waves without a block there.
+constexpr uint32_t kBlocksPerSmallTile = 4;
+__host__ __device__ constexpr uint32_t encLdsBytes(int P, bool spill, uint32_t ft, uint32_t tileBlocks) {
   return 4096u                                       // packed symbol table
       + 128u                                         // tile bookkeeping
-      + kBlocksPerTile * encStageCap(P, spill, ft) * 2u  // bitstream stage per half-wave
-      + kBlocksPerTile * 512u                        // symbol ring, 16 rows per half-wave
+      + tileBlocks * encStageCap(P, spill, ft) * 2u  // bitstream stage per half-wave
+      + tileBlocks * 512u                            // symbol ring, 16 rows per half-wave
       + 512u;                                        // scratch slots of non-emitting lanes
 }
 
@@ -110,7 +113,7 @@ struct EncodeArgs {
   uint32_t* ticket;          // kTicketCounters counters, kTicketStride words apart, zeroed before launch
   uint32_t* claims;          // [maxTiles][B] tile claim words, zeroed before launch (DGPU_SCHEDULE 2)
   uint32_t absentModulo;     // test hook: workgroups with index % absentModulo == 1 start ~0.5 ms late (0 = off)
-  uint16_t* spill;           // [gridDim.x][kBlocksPerTile][encSpillSlotWords(P)] (kSpill kernels only)
+  uint16_t* spill;           // [gridDim.x][blocks per tile][encSpillSlotWords(P)] (kSpill kernels only)
   uint32_t* outSize;         // [B] nullable
   uint32_t useChecksum;      // float header only
   const uint32_t* checksum;  // [B] nullable (float header only)
@@ -485,8 +488,9 @@ __device__ __forceinline__ uint32_t encodeRows(
   return outOff;
 }
 
-template <int P, uint32_t FT, bool kSpill>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_ans_encode(EncodeArgs a) {
+template <int P, uint32_t FT, bool kSpill, uint32_t kTB>
+__global__ __launch_bounds__(kTB * 32u) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_ans_encode(EncodeArgs a) {
+  constexpr uint32_t kThreads = kTB * 32u;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr uint32_t kCap = encStageCap(P, kSpill, FT);
   // bookkeeping sits BELOW the stages so that a stage overrun (only possible
@@ -495,7 +499,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   uint4* sTable = (uint4*)smem;
   TileShared* sh = (TileShared*)(smem + 4096);
   uint16_t* sStage = (uint16_t*)(smem + 4096 + 128);
-  uint8_t* sRing = smem + 4096 + 128 + kBlocksPerTile * kCap * 2u;
+  uint8_t* sRing = smem + 4096 + 128 + kTB * kCap * 2u;
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
@@ -508,8 +512,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   const uint32_t stageLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)stage;
   const uint32_t tableLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)sTable;
   // per-lane scratch slot for non-emitting lanes (512 bytes after the rings)
-  const uint32_t dummyLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(sRing + kBlocksPerTile * 512u) + tid * 2u;
-  uint16_t* spillSlot = kSpill ? a.spill + ((size_t)blockIdx.x * kBlocksPerTile + hw) * encSpillSlotWords(P) : nullptr;
+  const uint32_t dummyLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(sRing + kTB * 512u) + tid * 2u;
+  uint16_t* spillSlot = kSpill ? a.spill + ((size_t)blockIdx.x * kTB + hw) * encSpillSlotWords(P) : nullptr;
 
 #if DGPU_SCHEDULE == 2
   // Persistent workgroups, STATIC tile map with claim words.  Workgroup w owns the
@@ -547,14 +551,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   };
   bool firstOwned = false;
   if (tid == 0 && blockIdx.x < a.numTickets) firstOwned = claimTry(blockIdx.x);
-  for (uint32_t t = blockIdx.x + (tid + 1u) * gridDim.x; t < a.numTickets; t += 256u * gridDim.x) {
+  for (uint32_t t = blockIdx.x + (tid + 1u) * gridDim.x; t < a.numTickets; t += kThreads * gridDim.x) {
     (void)claimTry(t);  // later tickets: result looked up when the ticket comes up
   }
   for (uint32_t ticket0 = blockIdx.x; ticket0 < a.numTickets; ticket0 += gridDim.x) {
     const uint32_t tile0 = ticket0 / B;
     const uint32_t b = ticket0 - tile0 * B;
     {
-      const uint32_t tilesOfB = divUp(divUp(a.in.size(b), kBlockSize), kBlocksPerTile);
+      const uint32_t tilesOfB = divUp(divUp(a.in.size(b), kBlockSize), kTB);
       if (tile0 >= tilesOfB) continue;  // uniform (ragged batch)
     }
     if (tid == 0) {
@@ -632,7 +636,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 
     const uint32_t size = a.in.size(b);
     const uint32_t nb = divUp(size, kBlockSize);
-    const uint32_t numTiles = divUp(nb, kBlocksPerTile);
+    const uint32_t numTiles = divUp(nb, kTB);
 #if DGPU_SCHEDULE != 2
     if (tile >= numTiles) {  // uniform; nobody reads sh->ticket after the barrier below
 #if DGPU_SCHEDULE == 0
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     }
 #endif
 
-    sTable[tid] = a.encTable[b * kNumSymbols + tid];
+    for (uint32_t i = tid; i < kNumSymbols; i += kThreads) sTable[i] = a.encTable[b * kNumSymbols + i];
     ldsBarrier();
     DGPU_PHASE(1);
 
@@ -672,7 +676,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       }
     }
 
-    const uint32_t block = tile * kBlocksPerTile + hw;
+    const uint32_t block = tile * kTB + hw;
     const bool haveBlock = block < nb;
     uint32_t n = 0;
     if (haveBlock) {
@@ -680,7 +684,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       n = size - begin < kBlockSize ? size - begin : kBlockSize;
     }
     // wave-uniform: are both halves full blocks (and the input vector-aligned)?
-    const uint32_t firstBlockOfWave = tile * kBlocksPerTile + wave * 2u;
+    const uint32_t firstBlockOfWave = tile * kTB + wave * 2u;
     const bool waveFull = (uint64_t)(firstBlockOfWave + 2u) * kBlockSize <= (uint64_t)size &&
         (((uintptr_t)in & 15u) == 0);
 
@@ -719,10 +723,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 
     if (wave == 0) {
       // local exclusive scan of the padded sizes of the tile's 8 blocks
-      uint32_t myPadded = (lane < kBlocksPerTile) ? roundUp(sh->words[lane], kBlockAlignWords) : 0u;
+      uint32_t myPadded = (lane < kTB) ? roundUp(sh->words[lane], kBlockAlignWords) : 0u;
       uint32_t incl = waveInclusiveScan(myPadded, lane);
-      const uint32_t aggregate = __shfl(incl, kBlocksPerTile - 1, 64);
-      if (lane < kBlocksPerTile) sh->localOff[lane] = incl - myPadded;
+      const uint32_t aggregate = __shfl(incl, kTB - 1, 64);
+      if (lane < kTB) sh->localOff[lane] = incl - myPadded;
 
       uint64_t* desc = a.tileDesc + (size_t)b * a.maxTiles;
       if (lane == 0) {
@@ -765,13 +769,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       }
       // per-block word counts and start offsets (GpuANSEncode.cuh:595-608)
       uint2* blockWords = (uint2*)(ans + ansBlockWordsOffset(nb));
-      const uint32_t blk = tile * kBlocksPerTile + lane;
-      if (lane < kBlocksPerTile && blk < nb) {
+      const uint32_t blk = tile * kTB + lane;
+      if (lane < kTB && blk < nb) {
         const uint32_t begin = blk * kBlockSize;
         const uint32_t bn = size - begin < kBlockSize ? size - begin : kBlockSize;
         blockWords[blk] = make_uint2((bn << 16) | sh->words[lane], exclusive + (incl - myPadded));
       }
-      if (tile == numTiles - 1 && (nb & 1u) && lane == kBlocksPerTile) {
+      if (tile == numTiles - 1 && (nb & 1u) && lane == kTB) {
         blockWords[nb] = make_uint2(0u, 0u);  // alignment pad entry
       }
     }
@@ -804,14 +808,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 // (the histogram the reference fuses into splitFloat,
 // GpuFloatCompress.cuh:144, 352-364).  grid = (xBlocks, B), 256 threads;
 // hist must be zeroed first.
-template <uint32_t FT>
+template <uint32_t FT, uint32_t S>
 __global__ __launch_bounds__(256) void k_float_histogram(BatchView in, uint32_t* __restrict__ hist, uint32_t partial, HistFuse fuse) {
-  __shared__ uint32_t bins[kHistBlockWords];
+  __shared__ uint32_t bins[kNumSymbols * S];
   const uint32_t tid = threadIdx.x;
   const uint32_t b = blockIdx.y;
-  histZero(bins, tid);
+  histZero<S>(bins, tid);
   __syncthreads();
-  uint32_t* myBins = histMine(bins, tid);
+  uint32_t* myBins = histMine<S>(bins, tid);
 
   const uint32_t n = in.size(b);
   const uint8_t* inBytes = in.ptr(b);
@@ -824,17 +828,17 @@ __global__ __launch_bounds__(256) void k_float_histogram(BatchView in, uint32_t*
 
   auto addVec = [&](const uint4& x) {
     if (FT == kFloat32) {
-      histAdd(myBins, (x.x >> 23) & 0xffu);
-      histAdd(myBins, (x.y >> 23) & 0xffu);
-      histAdd(myBins, (x.z >> 23) & 0xffu);
-      histAdd(myBins, (x.w >> 23) & 0xffu);
+      histAdd<S>(myBins, (x.x >> 23) & 0xffu);
+      histAdd<S>(myBins, (x.y >> 23) & 0xffu);
+      histAdd<S>(myBins, (x.z >> 23) & 0xffu);
+      histAdd<S>(myBins, (x.w >> 23) & 0xffu);
     } else {
       constexpr uint32_t kShift = FT == kFloat16 ? 8u : 7u;
       const uint32_t xw[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        histAdd(myBins, (xw[j] >> kShift) & 0xffu);
-        histAdd(myBins, (xw[j] >> (16u + kShift)) & 0xffu);
+        histAdd<S>(myBins, (xw[j] >> kShift) & 0xffu);
+        histAdd<S>(myBins, (xw[j] >> (16u + kShift)) & 0xffu);
       }
     }
   };
@@ -855,10 +859,10 @@ __global__ __launch_bounds__(256) void k_float_histogram(BatchView in, uint32_t*
     uint32_t c;
     if (FT == kFloat32) c = (((const uint32_t*)inBytes)[i] >> 23) & 0xffu;
     else c = ((uint32_t)((const uint16_t*)inBytes)[i] >> (FT == kFloat16 ? 8u : 7u)) & 0xffu;
-    histAdd(myBins, c);
+    histAdd<S>(myBins, c);
   }
   __syncthreads();
-  histStore(hist, partial, fuse, b, tid, histFold(bins, tid));
+  histStore(hist, partial, fuse, b, tid, histFold<S>(bins, tid));
 }
 
 }  // namespace dgpu

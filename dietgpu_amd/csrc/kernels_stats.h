@@ -292,33 +292,36 @@ struct HistFuse {
 // can be a third of the data) and ds_add_u32 serialises lanes of one
 // instruction that hit the same address or bank, which made a per-wave
 // privatised layout run at ~2 lane-updates per clock per CU.  Layout used
-// instead: bin-major with kHistSlots = 32 lane slots per bin,
+// instead: bin-major with 32 lane slots per bin,
 //     word(bin, lane) = bin * 32 + (lane & 31),  bank = lane & 31
 // so within a 32-lane LDS pass every lane has a bank of its own whatever the
 // data: the pass is conflict-free by construction (16 slots allow 2-way
 // conflicts: raw bytes 68 -> 58 us, exponents 50.5 -> 49 us).  The four
 // wavefronts of a workgroup share the same 32 KiB (ds_add is atomic; different
 // waves are different instructions and merely interleave).
-#ifndef DGPU_HIST_SLOTS
-#define DGPU_HIST_SLOTS 32
-#endif
-constexpr uint32_t kHistSlots = DGPU_HIST_SLOTS;
-constexpr uint32_t kHistBlockWords = kNumSymbols * kHistSlots;  // 32 KiB
+// Workgroups that see little data (many small elements) use 8 slots instead:
+// zeroing and folding 32 KiB of bins costs more than their few conflicts.
+constexpr uint32_t kHistSlotsLarge = 32;
+constexpr uint32_t kHistSlotsSmall = 8;
 
+template <uint32_t S>
 __device__ __forceinline__ void histZero(uint32_t* bins, uint32_t tid) {
-  for (uint32_t i = tid; i < kHistBlockWords / 4u; i += 256u) ((uint4*)bins)[i] = make_uint4(0, 0, 0, 0);
+  for (uint32_t i = tid; i < kNumSymbols * S / 4u; i += 256u) ((uint4*)bins)[i] = make_uint4(0, 0, 0, 0);
 }
-// this lane's slot column; bin c lives at mine[c * kHistSlots]
+// this lane's slot column; bin c lives at mine[c * S]
+template <uint32_t S>
 __device__ __forceinline__ uint32_t* histMine(uint32_t* bins, uint32_t tid) {
-  return bins + (tid & (kHistSlots - 1u));
+  return bins + (tid & (S - 1u));
 }
-__device__ __forceinline__ void histAdd(uint32_t* mine, uint32_t c) { atomicAdd(&mine[c * kHistSlots], 1u); }
+template <uint32_t S>
+__device__ __forceinline__ void histAdd(uint32_t* mine, uint32_t c) { atomicAdd(&mine[c * S], 1u); }
 // total of bin `tid` over all slots
+template <uint32_t S>
 __device__ __forceinline__ uint32_t histFold(const uint32_t* bins, uint32_t tid) {
-  const uint4* p = (const uint4*)(bins + tid * kHistSlots);
+  const uint4* p = (const uint4*)(bins + tid * S);
   uint32_t sum = 0;
 #pragma unroll
-  for (uint32_t k = 0; k < kHistSlots / 4u; ++k) {
+  for (uint32_t k = 0; k < S / 4u; ++k) {
     const uint4 v = p[k];
     sum += v.x + v.y + v.z + v.w;
   }
@@ -328,11 +331,12 @@ __device__ __forceinline__ uint32_t histFold(const uint32_t* bins, uint32_t tid)
 // Histogram kernel: 16-byte loads with a byte-wise head/tail so any start
 // alignment works (the reference test uses stride size+11,
 // ANSStatisticsTest.cu:52-57).  grid = (xBlocks, B), 256 threads.
+template <uint32_t S>
 __device__ __forceinline__ void histAdd4(uint32_t* mine, uint32_t x) {
-  histAdd(mine, x & 0xff);
-  histAdd(mine, (x >> 8) & 0xff);
-  histAdd(mine, (x >> 16) & 0xff);
-  histAdd(mine, x >> 24);
+  histAdd<S>(mine, x & 0xff);
+  histAdd<S>(mine, (x >> 8) & 0xff);
+  histAdd<S>(mine, (x >> 16) & 0xff);
+  histAdd<S>(mine, x >> 24);
 }
 
 // `partial` != 0: this workgroup stores its 256 totals to hist[(b * gridDim.x + blockIdx.x) * 256 + bin]
@@ -370,14 +374,15 @@ __device__ __forceinline__ void histStore(uint32_t* __restrict__ hist, uint32_t 
   }
 }
 
+template <uint32_t S>
 __global__ __launch_bounds__(256) void k_histogram(BatchView in, uint32_t* __restrict__ hist, uint32_t partial, HistFuse fuse) {
-  __shared__ uint32_t bins[kHistBlockWords];
+  __shared__ uint32_t bins[kNumSymbols * S];
   const uint32_t tid = threadIdx.x;
   const uint32_t b = blockIdx.y;
-  histZero(bins, tid);
+  histZero<S>(bins, tid);
   __syncthreads();
 
-  uint32_t* myBins = histMine(bins, tid);
+  uint32_t* myBins = histMine<S>(bins, tid);
   const uint8_t* p = in.ptr(b);
   const uint32_t size = in.size(b);
 
@@ -388,33 +393,33 @@ __global__ __launch_bounds__(256) void k_histogram(BatchView in, uint32_t* __res
   const uint32_t numVec = remaining / 16u;
   const uint4* pv = (const uint4*)(p + head);
 
-  if (blockIdx.x == 0 && tid < head) histAdd(myBins, p[tid]);
+  if (blockIdx.x == 0 && tid < head) histAdd<S>(myBins, p[tid]);
 
   // four 16-byte loads in flight per lane (the kernel is HBM-latency bound otherwise)
   const uint32_t stride = gridDim.x * 256u;
   uint32_t i = blockIdx.x * 256u + tid;
   for (; i + 3u * stride < numVec; i += 4u * stride) {
     const uint4 v0 = streamLoad<DGPU_NT_HIST_LOADS != 0>(&pv[i]), v1 = streamLoad<DGPU_NT_HIST_LOADS != 0>(&pv[i + stride]), v2 = streamLoad<DGPU_NT_HIST_LOADS != 0>(&pv[i + 2u * stride]), v3 = streamLoad<DGPU_NT_HIST_LOADS != 0>(&pv[i + 3u * stride]);
-    histAdd4(myBins, v0.x); histAdd4(myBins, v0.y); histAdd4(myBins, v0.z); histAdd4(myBins, v0.w);
-    histAdd4(myBins, v1.x); histAdd4(myBins, v1.y); histAdd4(myBins, v1.z); histAdd4(myBins, v1.w);
-    histAdd4(myBins, v2.x); histAdd4(myBins, v2.y); histAdd4(myBins, v2.z); histAdd4(myBins, v2.w);
-    histAdd4(myBins, v3.x); histAdd4(myBins, v3.y); histAdd4(myBins, v3.z); histAdd4(myBins, v3.w);
+    histAdd4<S>(myBins, v0.x); histAdd4<S>(myBins, v0.y); histAdd4<S>(myBins, v0.z); histAdd4<S>(myBins, v0.w);
+    histAdd4<S>(myBins, v1.x); histAdd4<S>(myBins, v1.y); histAdd4<S>(myBins, v1.z); histAdd4<S>(myBins, v1.w);
+    histAdd4<S>(myBins, v2.x); histAdd4<S>(myBins, v2.y); histAdd4<S>(myBins, v2.z); histAdd4<S>(myBins, v2.w);
+    histAdd4<S>(myBins, v3.x); histAdd4<S>(myBins, v3.y); histAdd4<S>(myBins, v3.z); histAdd4<S>(myBins, v3.w);
   }
   for (; i < numVec; i += stride) {
     const uint4 v = streamLoad<DGPU_NT_HIST_LOADS != 0>(&pv[i]);
-    histAdd4(myBins, v.x);
-    histAdd4(myBins, v.y);
-    histAdd4(myBins, v.z);
-    histAdd4(myBins, v.w);
+    histAdd4<S>(myBins, v.x);
+    histAdd4<S>(myBins, v.y);
+    histAdd4<S>(myBins, v.z);
+    histAdd4<S>(myBins, v.w);
   }
 
   if (blockIdx.x == 0) {
     uint32_t t = numVec * 16u + tid;
-    if (t < remaining) histAdd(myBins, p[head + t]);
+    if (t < remaining) histAdd<S>(myBins, p[head + t]);
   }
   __syncthreads();
 
-  histStore(hist, partial, fuse, b, tid, histFold(bins, tid));
+  histStore(hist, partial, fuse, b, tid, histFold<S>(bins, tid));
 }
 
 // ---------------------------------------------------------------------------
