@@ -426,6 +426,31 @@ def test_fuzz_ragged_batches(dg, seed):
                 assert (tensor_to_words(ft, o) == w).all()
 
 
+def test_parameter_cache_eviction_and_no_temp(dg):
+    # 40 different pointer sets (the parameter cache holds 16) interleaved with repeats, no temp
+    # memory passed at all (library-owned overflow slab): every call must still be exact
+    rng = np.random.default_rng(5)
+    sets = []
+    for k in range(40):
+        ws = [refgen.generate_floats(O.BFLOAT16, int(rng.integers(1, 3)) * 4096 * 8 + 17 * k + i) for i in range(3)]
+        sets.append((ws, [words_to_tensor(O.BFLOAT16, w) for w in ws]))
+    order = list(range(40)) + [0, 1, 2, 39, 38, 0, 17, 17, 3]
+    for k in order:
+        ws, ts = sets[k]
+        comp, sizes, _ = dg.compress_data(True, ts, False, None, prob_bits=10)  # temp_mem=None
+        hs = sizes.cpu().numpy()
+        hc = comp.cpu().numpy()
+        outs = [torch.empty_like(t) for t in ts]
+        status = torch.zeros((len(ts),), dtype=torch.uint8, device=DEV)
+        dg.decompress_data(True, [comp[i, : hs[i]].clone() for i in range(len(ts))], outs, False, None, status, None,
+                           prob_bits=10)
+        assert status.cpu().numpy().all()
+        for i, w in enumerate(ws):
+            want = O.float_compress(O.BFLOAT16, w, 10)
+            assert hs[i] == want.size and (hc[i, : hs[i]] == want).all(), (k, i)
+            assert (tensor_to_words(O.BFLOAT16, outs[i]) == w).all()
+
+
 def test_concurrent_streams(dg):
     # Two streams compress and decompress different batches at the same time, repeatedly, without
     # host synchronisation in between: per-call state (tickets, claim words, descriptors, spill
