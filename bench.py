@@ -301,6 +301,22 @@ def main():
         torch.cuda.synchronize()
         return s.elapsed_time(e) / reps
 
+    # the same K steps with the parameter cache off (every call uploads its pointer / size arrays)
+    codec.lib.dgpu_debug_set_param_cache(0)
+    for _ in range(args.warmup):
+        codec.step()
+    fence()
+    t0u = time.perf_counter()
+    for _ in range(args.steps):
+        codec.step()
+    fence()
+    elapsed_uncached = time.perf_counter() - t0u
+    codec.lib.dgpu_debug_set_param_cache(1)
+    if distributed:
+        elapsed_uncached = D.max_over_ranks(elapsed_uncached, device)
+    for _ in range(args.warmup):
+        codec.step()  # refill the cache for the per-phase timings below
+
     if args.timeline:
         if rank == 0:
             print(json.dumps({"ms_per_step": round(elapsed / args.steps * 1e3, 4)}))
@@ -361,6 +377,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
+            "ms_per_step_param_upload_every_call": round(elapsed_uncached / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

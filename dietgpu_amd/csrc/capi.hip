@@ -228,6 +228,8 @@ class TempArena {
 //   * a hit records nothing; it remembers its stream, and evicting an entry that
 //     was hit since its last event synchronises that stream first (rare: LRU)
 //   * a hit from a stream other than the uploading one waits on `copied`
+std::atomic<bool> g_paramCacheEnabled{true};  // dgpu_debug_set_param_cache
+
 class ParamCache {
  public:
   struct Entry {
@@ -256,6 +258,7 @@ class ParamCache {
     std::vector<Entry*>& entries = perDevice_[dev];
     ++clock_;
     for (Entry* en : entries) {
+      if (!g_paramCacheEnabled.load()) break;  // measurement hook: upload on every call
       if (en->everUsed && en->hash == h && en->bytes == bytes && memcmp(en->host, block, bytes) == 0) {
         if (stream != en->uploadStream && hipEventQuery(en->copied) != hipSuccess) {
           e = hipStreamWaitEvent(stream, en->copied, 0);
@@ -974,6 +977,7 @@ uint32_t absentWorkgroupModulo() { return g_absentModulo.load(); }
 }  // namespace
 extern "C" {
 void dgpu_debug_set_absent_workgroups(uint32_t modulo) { g_absentModulo.store(modulo); }
+void dgpu_debug_set_param_cache(int on) { g_paramCacheEnabled.store(on != 0); }
 
 void dgpu_prof_enable(int on) {
   ProfState& p = prof();

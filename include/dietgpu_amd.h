@@ -238,6 +238,12 @@ int dgpu_prof_summary(char* buf, size_t cap);
  * running workgroups take over the tiles of workgroups that have not started. */
 void dgpu_debug_set_absent_workgroups(uint32_t modulo);
 
+/* Measurement hook: 0 makes every pointer-array call upload its parameter block
+ * (no reuse of blocks already resident on the device); 1 (default) restores the
+ * cache.  bench.py uses it to report the step time without the cache next to the
+ * steady-state one. */
+void dgpu_debug_set_param_cache(int on);
+
 #ifdef __cplusplus
 }
 #endif
