@@ -426,6 +426,33 @@ def test_fuzz_ragged_batches(dg, seed):
                 assert (tensor_to_words(ft, o) == w).all()
 
 
+def test_maximum_batch_size(dg):
+    # 65535 elements in one call (the API's maximum; grid.y limit), a few hundred bytes each
+    B = 65535
+    rng = np.random.default_rng(123)
+    base = rng.integers(0, 48, 1 << 20, dtype=np.uint8)
+    sizes = rng.integers(1, 400, B)
+    offs = rng.integers(0, (1 << 20) - 400, B)
+    buf = torch.from_numpy(base).to(DEV)
+    ts = [buf[int(o) : int(o) + int(n)] for o, n in zip(offs, sizes)]
+    # inputs must be 4-byte aligned for the raw codec: use aligned offsets
+    offs = (offs // 4) * 4
+    ts = [buf[int(o) : int(o) + int(n)] for o, n in zip(offs, sizes)]
+    comp, csz, _ = dg.compress_data(False, ts, False, prob_bits=10)
+    hs = csz.cpu().numpy()
+    hc = comp.cpu().numpy()
+    for i in list(range(0, B, 997)) + [B - 1]:
+        x = base[int(offs[i]) : int(offs[i]) + int(sizes[i])]
+        want = O.ans_encode(x, 10)
+        assert hs[i] == want.size and (hc[i, : hs[i]] == want).all(), i
+    outs = [torch.empty((int(n),), dtype=torch.uint8, device=DEV) for n in sizes]
+    status = torch.zeros((B,), dtype=torch.uint8, device=DEV)
+    dg.decompress_data(False, [comp[i] for i in range(B)], outs, False, None, status, None, prob_bits=10)
+    assert bool(status.all().item())
+    for i in list(range(0, B, 1499)) + [B - 1]:
+        assert torch.equal(outs[i], ts[i]), i
+
+
 def test_parameter_cache_eviction_and_no_temp(dg):
     # 40 different pointer sets (the parameter cache holds 16) interleaved with repeats, no temp
     # memory passed at all (library-owned overflow slab): every call must still be exact
