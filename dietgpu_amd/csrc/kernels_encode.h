@@ -9,15 +9,15 @@
 //     therefore encodes TWO blocks at once: lanes 0-31 own block 2w, lanes
 //     32-63 own block 2w+1.  One 64-bit ballot per row serves both halves;
 //     each half takes its own 32-bit slice for the prefix popcount.
-//   * Symbols reach the lanes through a 512-byte LDS ring per block (16 rows):
+//   * Symbols reach the lanes through a 512-byte LDS ring per block (16 rows; 8 for fp32):
 //     16-byte global loads, one ds_write_b128, then a ds_read_u8 per row whose
 //     result is turned into the LDS address of the symbol's table entry right
 //     away.  Neither that nor the table lookup depends on the rANS state, so
 //     both run ahead of the dependent chain.
 //   * For the float codec the SOURCE of a chunk is the float words themselves:
-//     the lane splits its 16 words with packed byte tricks (v_perm / v_bfi /
-//     v_alignbit), stores the 16 non-compressed bytes straight into the
-//     archive and hands the 16 exponent bytes to the ring.  The exponent plane
+//     the lane splits its 16 words with packed byte tricks (v_perm, packed-u16
+//     shift + multiply-add, v_alignbit), stores the 16 non-compressed bytes
+//     straight into the archive and hands the 16 exponent bytes to the ring.  The exponent plane
 //     never exists in HBM (the reference writes and re-reads it).
 //   * The row step of a full block is branch-free straight-line code: lanes
 //     that do not emit store to a private scratch slot, so no exec-mask
