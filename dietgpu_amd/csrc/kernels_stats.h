@@ -145,28 +145,29 @@ __device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const u
     __syncthreads();
     const int qSum = (int)(sWave[0] + sWave[1] + sWave[2] + sWave[3]);
 
-    // rank in descending order = number of keys greater than mine
-    uint32_t rank = 0;
-    const uint4* k4 = (const uint4*)sKeys;
-#pragma unroll 8
-    for (int i = 0; i < 64; ++i) {
-      uint4 k = k4[i];
-      rank += (k.x > key) + (k.y > key) + (k.z > key) + (k.w > key);
-    }
-    sSorted[rank] = key;
-    __syncthreads();
-
-    // thread r now owns the entry of rank r
-    const uint32_t rk = sSorted[tid];
-    const uint32_t rsym = rk & 0xffffu;
-    uint32_t rq = rk >> 16;
-
     int diff = (int)W - qSum;  // :256
-    if (diff > 0) {
+    if (diff >= 0) {  // uniform
       // :258-274.  Each loop trip of the reference adds 1 to every entry whose
-      // SYMBOL index is < min(diff, 256); closed form of that loop:
-      rq += (uint32_t)diff / 256u + ((rsym < ((uint32_t)diff % 256u)) ? 1u : 0u);
-    } else if (diff < 0) {
+      // SYMBOL index is < min(diff, 256): the result does not depend on the sorted
+      // order at all, so the sort (:229-241) is skipped.  Closed form of the loop:
+      pdf = q + (uint32_t)diff / 256u + ((tid < ((uint32_t)diff % 256u)) ? 1u : 0u);
+    } else {
+      // rank in descending order = number of keys greater than mine
+      uint32_t rank = 0;
+      const uint4* k4 = (const uint4*)sKeys;
+#pragma unroll 8
+      for (int i = 0; i < 64; ++i) {
+        uint4 k = k4[i];
+        rank += (k.x > key) + (k.y > key) + (k.z > key) + (k.w > key);
+      }
+      sSorted[rank] = key;
+      __syncthreads();
+
+      // thread r now owns the entry of rank r
+      const uint32_t rk = sSorted[tid];
+      const uint32_t rsym = rk & 0xffffu;
+      uint32_t rq = rk >> 16;
+
       // :275-315  subtract 1 from the smallest entries that are still > 1
       diff = -diff;
       while (diff > 0) {
@@ -177,11 +178,11 @@ __device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const u
         if ((int)tid >= start && (int)tid < numGt1) rq -= 1;
         diff -= iter;
       }
-    }
 
-    sPdf[rsym] = rq;  // :318-334 un-sort
-    __syncthreads();
-    pdf = sPdf[tid];
+      sPdf[rsym] = rq;  // :318-334 un-sort
+      __syncthreads();
+      pdf = sPdf[tid];
+    }
 
     // exclusive scan -> cdf  (:336-341)
     uint32_t incl = waveInclusiveScan(pdf, lane);
