@@ -177,6 +177,15 @@ def algorithmic_bytes(kernel, codec, comp_total):
     }.get(kernel)
 
 
+def baseline_metric():
+    """BASELINE.json's wording of the metric this line reports (None if the file is not there)."""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f).get("metric")
+    except (OSError, ValueError):
+        return None
+
+
 def measured_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (cannot be collected inside this
     process: rocprofv3 wraps the command).  None when no pass exists for this workload."""
@@ -371,6 +380,7 @@ def main():
             step_alg = 2 * (E + comp_total)
         out = {
             "metric": "rans_encode_decode_GBps",
+            "baseline_metric": baseline_metric(),
             "value": round(value, 2),
             "unit": "GB/s",
             "n_gpus": world,
