@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Headline benchmark: batched rANS float codec, encode + decode, on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bf16|u8|fp16]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bf16|u8|fp16|fp32]
+
+`--gpus N` with N > 1 and no torchrun environment starts the N ranks itself
+(torch.distributed.run, one process per GPU, RCCL); under the driver's own
+torchrun it checks WORLD_SIZE == N.  It refuses to run on fewer GPUs than asked.
 
 Workload (BASELINE.json `metric`: "rANS encode+decode GB/s on 256x1 MiB bf16"):
 256 tensors x 524288 bfloat16 ~ N(0,1) per GPU, probBits
@@ -63,9 +67,10 @@ def make_workload(kind, batch, seed, device, n=512 * 1024):
     if kind == "u8":
         import refgen
 
-        rows = refgen.zipf_bytes(8, 1 << 20, seed=seed)
-        t = torch.from_numpy(np.tile(rows, (batch // 8, 1))).to(device)
-        return t, 0, 1, 10, f"{batch}x1MiB uint8 Zipf(1.2), raw rANS, probBits 10 (BASELINE config 2)"
+        # every row is its own stream, default_rng(1234 + b)
+        rows = refgen.zipf_bytes(batch, 1 << 20, seed=seed)
+        t = torch.from_numpy(rows).to(device)
+        return t, 0, 1, 10, f"{batch}x1MiB uint8 Zipf(1.2) (independent rows, default_rng(1234+b)), raw rANS, probBits 10 (BASELINE config 2)"
     raise ValueError(kind)
 
 
@@ -208,40 +213,56 @@ def cpu_baseline(kind, prob_bits, budget_s=12.0):
     rows = max(cores, 16)
     n = 512 * 1024
     if kind == "u8":
-        data = np.tile(refgen.zipf_bytes(8, 1 << 20), (max(rows // 8, 1), 1))
-        rows = data.shape[0]
-        enc = lambda: O.ans_encode_batch(data, prob_bits, threads=cores)
-        dec = lambda c: O.ans_decode_batch(c, data.shape[1], prob_bits, threads=cores)
-        nbytes = data.size
+        data = refgen.zipf_bytes(rows, 1 << 20)  # rows of the bench workload itself: default_rng(1234 + b)
+        width = data.shape[1]
+        enc = lambda d, th: O.ans_encode_batch(d, prob_bits, threads=th)
+        dec = lambda c, th: O.ans_decode_batch(c, width, prob_bits, threads=th)
+        row_bytes = width
     else:
-        ft = O.BFLOAT16 if kind == "bf16" else O.FLOAT16
-        data = refgen.normal_bf16(rows, n) if kind == "bf16" else refgen.sparse_fp16(rows, n)
-        enc = lambda: O.float_compress_batch(ft, data, prob_bits, threads=cores)
-        dec = lambda c: O.float_decompress_batch(ft, c, n, prob_bits, threads=cores)
-        nbytes = data.size * 2
-    comp, _ = enc()  # warm
-    reps, t_enc, t_dec = 0, 0.0, 0.0
-    t_start = time.perf_counter()
-    while True:
-        t0 = time.perf_counter()
-        comp, _ = enc()
-        t1 = time.perf_counter()
-        out = dec(comp)
-        t2 = time.perf_counter()
-        t_enc += t1 - t0
-        t_dec += t2 - t1
-        reps += 1
-        if time.perf_counter() - t_start > budget_s or reps >= 50:
-            break
-    assert (out == data).all()
+        ft = {"bf16": O.BFLOAT16, "fp16": O.FLOAT16, "fp32": O.FLOAT32}[kind]
+        if kind == "bf16":
+            data = refgen.normal_bf16(rows, n)
+        elif kind == "fp16":
+            data = refgen.sparse_fp16(rows, n)
+        else:
+            n = n // 2
+            data = np.random.default_rng(1234).standard_normal((rows, n), dtype=np.float32).view(np.uint32)
+        enc = lambda d, th: O.float_compress_batch(ft, d, prob_bits, threads=th)
+        dec = lambda c, th: O.float_decompress_batch(ft, c, n, prob_bits, threads=th)
+        row_bytes = n * data.itemsize
+
+    def run(d, threads, budget):
+        comp, _ = enc(d, threads)  # warm
+        reps, t_enc, t_dec = 0, 0.0, 0.0
+        t_start = time.perf_counter()
+        while True:
+            t0 = time.perf_counter()
+            comp, _ = enc(d, threads)
+            t1 = time.perf_counter()
+            out = dec(comp, threads)
+            t2 = time.perf_counter()
+            t_enc += t1 - t0
+            t_dec += t2 - t1
+            reps += 1
+            if time.perf_counter() - t_start > budget or reps >= 50:
+                break
+        assert (out == d).all()
+        nbytes = d.shape[0] * row_bytes * reps
+        return 2 * nbytes / (t_enc + t_dec) / 1e9, nbytes / t_enc / 1e9, nbytes / t_dec / 1e9, reps
+
+    allc, allc_enc, allc_dec, reps = run(data, cores, budget_s)
+    # SURVEY.md section 8(d) also asks for the single-thread figure: 4 rows, one thread
+    one, one_enc, one_dec, reps1 = run(data[:4], 1, budget_s / 3)
     return {
-        "value": round(2 * nbytes * reps / (t_enc + t_dec) / 1e9, 4),
+        "value": round(allc, 4),
         "unit": "GB/s",
         "cores": cores,
         "kind": "port",
         "sample": f"{rows} rows of the same workload x {reps} reps, oracle/ C restatement, "
-                  f"{cores} pthreads (one row per task); encode {nbytes * reps / t_enc / 1e9:.3f} GB/s, "
-                  f"decode {nbytes * reps / t_dec / 1e9:.3f} GB/s",
+                  f"{cores} pthreads (one row per task); encode {allc_enc:.3f} GB/s, decode {allc_dec:.3f} GB/s",
+        "single_thread": {"value": round(one, 4), "unit": "GB/s", "cores": 1,
+                          "sample": f"4 rows x {reps1} reps on one thread; encode {one_enc:.3f} GB/s, "
+                                    f"decode {one_dec:.3f} GB/s"},
     }
 
 
@@ -259,14 +280,41 @@ def main():
     ap.add_argument("--timeline", action="store_true",
                     help="only the timed steps (no per-phase timing / kernel profile): for rocprofv3 timelines")
     args = ap.parse_args()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+
+    # DGPU_BENCH_ONE_DEVICE=1 (with --dist-backend gloo): every rank on GPU 0 -- lets the N > 1 code path
+    # be exercised on a single-GPU box; never used for measurements
+    one_device = os.environ.get("DGPU_BENCH_ONE_DEVICE") == "1"
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` on its own: start the N ranks ourselves, one per GPU, the way the
+        # driver does (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...)
+        have = torch.cuda.device_count()
+        if have < args.gpus and not one_device:
+            sys.exit(f"bench.py: --gpus {args.gpus} asked for, but this node has {have} GPU(s); refusing to "
+                     f"report a smaller job under that flag")
+        import socket
+        import subprocess
+
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                 f"(python bench.py --gpus N does it by itself)")
     distributed = world > 1
-    # DGPU_BENCH_ONE_DEVICE=1 (with --dist-backend gloo): every rank on GPU 0 -- lets the N > 1 code path
-    # be exercised on a single-GPU box; never used for measurements
-    dev_index = 0 if os.environ.get("DGPU_BENCH_ONE_DEVICE") == "1" else local_rank
+    if not one_device and torch.cuda.device_count() < world:
+        sys.exit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
+    dev_index = 0 if one_device else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     import dietgpu_amd as dg
@@ -296,8 +344,13 @@ def main():
         codec.step()
     fence()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [elapsed / args.steps * 1e3]
+    world_seen = 1
     if distributed:
+        per_rank_ms = [t / args.steps * 1e3 for t in D.gather_scalars(elapsed, device)]
         elapsed = D.max_over_ranks(elapsed, device)
+        world_seen = dist.get_world_size()
+        assert world_seen == world and len(per_rank_ms) == world
     codec.verify()
 
     # separate encode / decode timings (HIP events on the launch stream)
@@ -384,6 +437,9 @@ def main():
             "value": round(value, 2),
             "unit": "GB/s",
             "n_gpus": world,
+            "world_size_seen_by_backend": world_seen,
+            "dist_backend": args.dist_backend if distributed else None,
+            "per_rank_ms_per_step": [round(t, 4) for t in per_rank_ms],
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),

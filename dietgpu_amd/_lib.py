@@ -36,6 +36,9 @@ _SIGS = {
     "dgpu_float_get_compressed_info_device": (i32, [vp, u32, vp, vp, vp, vp]),
     "dgpu_ans_histogram_batch_stride": (i32, [u32, vp, u32, u32, vp, vp]),
     "dgpu_ans_calc_weights": (i32, [u32, i32, vp, u32, vp, vp, vp]),
+    "dgpu_release_stream_state": (i32, [vp]),
+    "dgpu_release_all_stream_state": (i32, []),
+    "dgpu_debug_stream_state_count": (u32, []),
     "dgpu_prof_enable": (None, [i32]),
     "dgpu_prof_reset": (None, []),
     "dgpu_prof_summary": (i32, [C.c_char_p, sz]),

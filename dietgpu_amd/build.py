@@ -9,15 +9,19 @@ LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.environ.get("DGPU_LIB") or os.path.join(LIB_DIR, "libdietgpu_amd.so")
 
 _SOURCES = ["capi.hip"]
-_DEPS = ["format.h", "kernels_stats.h", "kernels_encode.h", "kernels_decode.h", "kernels_float.h",
-         "capi.hip", os.path.join("..", "..", "include", "dietgpu_amd.h")]
+
+
+def _deps():
+    """Everything the library is compiled from: csrc/*.h, csrc/*.hip and the public C header."""
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".hip")))
+    return [os.path.join(CSRC, f) for f in names] + [os.path.join(_HERE, "..", "include", "dietgpu_amd.h")]
 
 
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in _DEPS)
+    return any(os.path.getmtime(d) > t for d in _deps())
 
 
 def build(force=False, verbose=False):

@@ -98,64 +98,169 @@ class KernelTimer {
   } while (0)
 
 // ---------------------------------------------------------------------------
-// Temp memory: bump allocation out of the caller's region; if it does not fit,
-// fall back to hipMalloc with a warning (StackDeviceMemory.cpp:119-139).
-// Library-owned overflow memory, one grow-only slab per (device, stream).  When
-// the caller's temp memory is missing or too small the reference falls back to
-// cudaMalloc + cudaFree around every call (synchronising).  Here the overflow
-// comes from a slab that is kept between calls: calls on one stream execute in
-// order, so the slab can be re-used from offset 0 by every call without any
-// synchronisation.  A slab that has to grow is retired (freed after a stream
-// synchronise at the next growth), never freed under kernels that may use it.
-class OverflowPool {
+// Library-owned device state per (device, stream): everything a call needs that
+// must outlive it or be zero when it starts.
+//   * overflow slab: when the caller's temp memory is missing or too small the
+//     reference falls back to cudaMalloc + cudaFree around every call
+//     (synchronising, StackDeviceMemory.cpp:119-139).  Here the overflow comes
+//     from a grow-only slab that is kept between calls: calls on one stream
+//     execute in order, so every call can carve the slab from offset 0 without
+//     synchronising.  A slab that has to grow in the middle of a call is RETIRED,
+//     never freed under the call: allocations handed out earlier in the same call
+//     live in it and their kernels have not even been launched yet.  Retired slabs
+//     are freed by the NEXT call that needs overflow memory, after a stream
+//     synchronise.
+//   * arrival counters / accumulate-mode histogram counters of the histogram ->
+//     normalisation hand-off, zero at rest.
+// A call that touches this state holds `busy` from its first use until it has
+// enqueued everything: two host threads enqueueing on the same stream would
+// otherwise carve the same slab bytes for two calls whose kernels interleave.
+// The registry is bounded: beyond kMaxStreams entries per process the idle ones
+// are released after a device synchronise (streams come and go in long-running
+// processes; their handles cannot be observed dying).
+constexpr uint32_t kAccElements = 64;  // batches up to this size may use the accumulate-by-atomics histogram
+struct StreamState {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::mutex busy;          // held by the call using this state
+  uint64_t lastUse = 0;
+  // overflow slab
+  uint8_t* slab = nullptr;
+  size_t slabCap = 0;
+  std::vector<void*> retired;
+  // 65536 arrival counters + kAccElements x 256 histogram counters, zero at rest
+  uint32_t* counters = nullptr;
+
+  void releaseDeviceMemory() {
+    for (void* p : retired) (void)hipFree(p);
+    retired.clear();
+    if (slab) (void)hipFree(slab);
+    if (counters) (void)hipFree(counters);
+    slab = nullptr;
+    slabCap = 0;
+    counters = nullptr;
+  }
+};
+
+class StreamRegistry {
  public:
-  struct Slab {
-    uint8_t* base = nullptr;
-    size_t cap = 0;
-    std::vector<void*> retired;
-  };
-  // Returns memory for [head, head + need) of this stream's slab, growing it if necessary;
-  // *head is advanced.  A grown slab restarts at offset 0 (earlier pointers stay valid: retired).
-  void* take(hipStream_t stream, size_t* head, size_t need, hipError_t* err) {
+  static constexpr size_t kMaxStreams = 32;
+  // Returns the state of (current device, stream), creating it if necessary.
+  StreamState* get(hipStream_t stream, hipError_t* err) {
     std::lock_guard<std::mutex> g(mu_);
     int dev = 0;
     *err = hipGetDevice(&dev);
     if (*err != hipSuccess) return nullptr;
-    Slab& s = slabs_[std::make_pair(dev, stream)];
-    if (*head + need > s.cap) {
-      if (!s.retired.empty()) {
-        (void)hipStreamSynchronize(stream);
-        for (void* p : s.retired) (void)hipFree(p);
-        s.retired.clear();
-      }
-      const size_t cap = std::max<size_t>(std::max(2 * s.cap, need + (need >> 2)), (size_t)8 << 20);
-      void* p = nullptr;
-      *err = hipMalloc(&p, cap);
-      if (*err != hipSuccess) return nullptr;
-      if (s.base) s.retired.push_back(s.base);
-      s.base = (uint8_t*)p;
-      s.cap = cap;
-      *head = 0;
+    auto key = std::make_pair(dev, stream);
+    auto it = states_.find(key);
+    if (it == states_.end()) {
+      if (states_.size() >= kMaxStreams) trimLocked();
+      StreamState* s = new StreamState();
+      s->device = dev;
+      s->stream = stream;
+      it = states_.emplace(key, s).first;
     }
-    void* out = s.base + *head;
-    *head += need;
-    return out;
+    it->second->lastUse = ++clock_;
+    return it->second;
+  }
+  // Frees the device memory kept for `stream` on the current device (all streams
+  // of all devices if `all`).  Synchronises first.  Returns the number of states released.
+  int release(hipStream_t stream, bool all) {
+    std::lock_guard<std::mutex> g(mu_);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    int n = 0;
+    for (auto it = states_.begin(); it != states_.end();) {
+      StreamState* s = it->second;
+      const bool match = all || (it->first.first == dev && it->first.second == stream);
+      if (match && s->busy.try_lock()) {
+        int prev = dev;
+        (void)hipSetDevice(s->device);
+        (void)hipDeviceSynchronize();
+        s->releaseDeviceMemory();
+        (void)hipSetDevice(prev);
+        s->busy.unlock();
+        delete s;
+        it = states_.erase(it);
+        ++n;
+      } else {
+        ++it;
+      }
+    }
+    return n;
+  }
+  size_t size() {
+    std::lock_guard<std::mutex> g(mu_);
+    return states_.size();
   }
 
  private:
+  // Drops the least recently used half of the idle states (device synchronise first:
+  // nothing enqueued earlier can still be using their memory afterwards).
+  void trimLocked() {
+    std::vector<std::pair<uint64_t, std::pair<int, hipStream_t>>> idle;
+    for (auto& kv : states_) idle.push_back({kv.second->lastUse, kv.first});
+    std::sort(idle.begin(), idle.end());
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    size_t dropped = 0;
+    for (auto& e : idle) {
+      if (dropped >= kMaxStreams / 2) break;
+      StreamState* s = states_[e.second];
+      if (!s->busy.try_lock()) continue;
+      (void)hipSetDevice(s->device);
+      (void)hipDeviceSynchronize();
+      s->releaseDeviceMemory();
+      s->busy.unlock();
+      delete s;
+      states_.erase(e.second);
+      ++dropped;
+    }
+    (void)hipSetDevice(cur);
+  }
   std::mutex mu_;
-  std::map<std::pair<int, hipStream_t>, Slab> slabs_;
+  uint64_t clock_ = 0;
+  std::map<std::pair<int, hipStream_t>, StreamState*> states_;
 };
 
-OverflowPool& overflowPool() {
-  static OverflowPool* p = new OverflowPool();  // intentionally leaked: no teardown-order issues
-  return *p;
+StreamRegistry& streamRegistry() {
+  static StreamRegistry* r = new StreamRegistry();  // intentionally leaked: no teardown-order issues
+  return *r;
 }
 
+// One call's hold on the stream state (taken lazily: calls whose temp memory
+// suffices and that need no library-owned counters never touch it).
+class StreamLease {
+ public:
+  explicit StreamLease(hipStream_t stream) : stream_(stream) {}
+  StreamLease(const StreamLease&) = delete;
+  StreamLease& operator=(const StreamLease&) = delete;
+  ~StreamLease() {
+    if (state_) state_->busy.unlock();
+  }
+  StreamState* state(hipError_t* err) {
+    if (!state_) {
+      StreamState* s = streamRegistry().get(stream_, err);
+      if (!s) return nullptr;
+      s->busy.lock();
+      state_ = s;
+    }
+    *err = hipSuccess;
+    return state_;
+  }
+  hipStream_t stream() const { return stream_; }
+
+ private:
+  hipStream_t stream_;
+  StreamState* state_ = nullptr;
+};
+
+// Temp memory: bump allocation out of the caller's region; what does not fit
+// comes from the stream's overflow slab with a warning (StackDeviceMemory.cpp:119-139).
 class TempArena {
  public:
-  TempArena(void* base, size_t bytes, hipStream_t stream)
-      : base_((uint8_t*)base), bytes_(base ? bytes : 0), stream_(stream) {
+  TempArena(void* base, size_t bytes, StreamLease& lease)
+      : base_((uint8_t*)base), bytes_(base ? bytes : 0), lease_(lease) {
     // honour the 256-byte granularity even if the caller's pointer is odd
     size_t mis = ((uintptr_t)base_) % kTempAlign;
     if (base_ && mis) {
@@ -187,19 +292,50 @@ class TempArena {
               bytes_, requested_);
       warned_ = true;
     }
-    return (T*)overflowPool().take(stream_, &overflowHead_, need, err);
+    return (T*)overflow(need, err);
   }
 
   size_t requested() const { return requested_; }
 
  private:
+  void* overflow(size_t need, hipError_t* err) {
+    StreamState* s = lease_.state(err);
+    if (!s) return nullptr;
+    if (!overflowUsed_) {
+      overflowUsed_ = true;
+      // first overflow allocation of this call: slabs retired by EARLIER calls can go
+      // (their kernels precede everything this call enqueues on the stream)
+      if (!s->retired.empty()) {
+        *err = hipStreamSynchronize(lease_.stream());
+        if (*err != hipSuccess) return nullptr;
+        for (void* p : s->retired) (void)hipFree(p);
+        s->retired.clear();
+      }
+    }
+    if (overflowHead_ + need > s->slabCap) {
+      const size_t cap = std::max<size_t>(std::max(2 * s->slabCap, need + (need >> 2)), (size_t)8 << 20);
+      void* p = nullptr;
+      *err = hipMalloc(&p, cap);
+      if (*err != hipSuccess) return nullptr;
+      // the old slab may hold allocations of THIS call: retire it, never free it here
+      if (s->slab) s->retired.push_back(s->slab);
+      s->slab = (uint8_t*)p;
+      s->slabCap = cap;
+      overflowHead_ = 0;
+    }
+    void* out = s->slab + overflowHead_;
+    overflowHead_ += need;
+    return out;
+  }
+
   uint8_t* base_;
   size_t bytes_;
-  hipStream_t stream_;
+  StreamLease& lease_;
   size_t head_ = 0;
   size_t overflowHead_ = 0;
   size_t requested_ = 0;
   bool warned_ = false;
+  bool overflowUsed_ = false;
 };
 
 #define DGPU_ALLOC(var, T, arena, count)                                     \
@@ -225,8 +361,8 @@ class TempArena {
 //   * an entry is pinned (not evictable) while a call is being enqueued with it
 //   * a miss records `released` on the caller's stream when the call has been
 //     enqueued; eviction waits for it (it is 8 calls old by then)
-//   * a hit records nothing; it remembers its stream, and evicting an entry that
-//     was hit since its last event synchronises that stream first (rare: LRU)
+//   * a hit records nothing; the entry remembers every stream that hit it, and
+//     evicting it synchronises those streams first (rare: LRU)
 //   * a hit from a stream other than the uploading one waits on `copied`
 std::atomic<bool> g_paramCacheEnabled{true};  // dgpu_debug_set_param_cache
 
@@ -243,8 +379,8 @@ class ParamCache {
     hipEvent_t copied = nullptr;
     hipEvent_t released = nullptr;
     hipStream_t uploadStream = nullptr;
-    hipStream_t lastHitStream = nullptr;
-    bool hitSinceRelease = false;
+    std::vector<hipStream_t> hitStreams;  // every stream that hit this entry since its upload
+    bool syncAllBeforeReuse = false;      // completion could not be tracked: device synchronise before reuse
     bool everUsed = false;
   };
 
@@ -266,8 +402,9 @@ class ParamCache {
         }
         en->lastUse = clock_;
         en->pins++;
-        en->hitSinceRelease = true;
-        en->lastHitStream = stream;
+        if (std::find(en->hitStreams.begin(), en->hitStreams.end(), stream) == en->hitStreams.end()) {
+          en->hitStreams.push_back(stream);
+        }
         *out = en;
         *miss = false;
         return hipSuccess;
@@ -285,15 +422,24 @@ class ParamCache {
       entries.push_back(victim);
     }
     if (victim->everUsed) {
-      if (victim->hitSinceRelease) {
-        if (hipStreamSynchronize(victim->lastHitStream) != hipSuccess) {
+      // kernels of every call that used this block must be done with it: hits record
+      // nothing, so synchronise each stream that hit it (rare: LRU eviction of a block
+      // that was still in use a few calls ago)
+      bool needDeviceSync = victim->syncAllBeforeReuse;
+      for (hipStream_t hs : victim->hitStreams) {
+        if (needDeviceSync) break;
+        if (hipStreamSynchronize(hs) != hipSuccess) {
           (void)hipGetLastError();
-          e = hipDeviceSynchronize();  // the stream may be gone
-          if (e != hipSuccess) return e;
+          needDeviceSync = true;  // the stream may be gone
         }
       }
-      e = hipEventSynchronize(victim->released);
-      if (e != hipSuccess) return e;
+      if (needDeviceSync) {
+        e = hipDeviceSynchronize();
+        if (e != hipSuccess) return e;
+      } else {
+        e = hipEventSynchronize(victim->released);
+        if (e != hipSuccess) return e;
+      }
     }
     if (victim->cap < bytes) {
       if (victim->host) (void)hipHostFree(victim->host);
@@ -323,8 +469,8 @@ class ParamCache {
     if (e != hipSuccess) return e;
     victim->everUsed = true;
     victim->uploadStream = stream;
-    victim->hitSinceRelease = false;
-    victim->lastHitStream = nullptr;
+    victim->hitStreams.clear();
+    victim->syncAllBeforeReuse = false;
     victim->lastUse = clock_;
     victim->pins++;
     *out = victim;
@@ -336,9 +482,8 @@ class ParamCache {
     std::lock_guard<std::mutex> g(mu_);
     if (miss) {
       if (hipEventRecord(en->released, stream) != hipSuccess) {
-        // cannot track completion: never match or reuse this entry without a full sync
-        en->hitSinceRelease = true;
-        en->lastHitStream = stream;
+        // cannot track completion: never reuse this entry without a full sync
+        en->syncAllBeforeReuse = true;
       }
     }
     en->pins--;
@@ -609,24 +754,19 @@ bool histAccumulates(uint32_t B, uint32_t maxBytes) {
 // (HistFuse): 65536 u32 per (device, stream), zero at rest -- the kernel that uses
 // them puts them back to zero.  Keyed by stream because calls on one stream are
 // ordered while calls on different streams may overlap.
-constexpr uint32_t kAccElements = 64;  // batches up to this size may use the accumulate-by-atomics histogram
-int arrivalCounters(hipStream_t stream, uint32_t** out, uint32_t** acc) {
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, uint32_t*> counters;
-  std::lock_guard<std::mutex> g(mu);
-  int dev = 0;
-  DGPU_HIP(hipGetDevice(&dev));
-  auto key = std::make_pair(dev, stream);
-  auto it = counters.find(key);
-  if (it == counters.end()) {
+int arrivalCounters(StreamLease& lease, uint32_t** out, uint32_t** acc) {
+  hipError_t e = hipSuccess;
+  StreamState* s = lease.state(&e);
+  if (!s) return fail(DGPU_ERR_HIP, std::string("stream state: ") + hipGetErrorString(e));
+  if (!s->counters) {
     uint32_t* p = nullptr;
     const size_t words = 65536 + (size_t)kAccElements * kNumSymbols;
     DGPU_HIP(hipMalloc((void**)&p, words * sizeof(uint32_t)));
     DGPU_HIP(hipMemset(p, 0, words * sizeof(uint32_t)));  // once per (device, stream); synchronous
-    it = counters.emplace(key, p).first;
+    s->counters = p;
   }
-  *out = it->second;
-  *acc = it->second + 65536;
+  *out = s->counters;
+  *acc = s->counters + 65536;
   return DGPU_OK;
 }
 
@@ -638,7 +778,7 @@ int arrivalCounters(hipStream_t stream, uint32_t** out, uint32_t** acc) {
 // one of each element sums and normalises them and clears the tile descriptors +
 // ticket for the encode kernel.
 int encodeCommon(
-    TempArena& arena, hipStream_t stream, int P, bool useChecksum, uint32_t B,
+    TempArena& arena, StreamLease& lease, hipStream_t stream, int P, bool useChecksum, uint32_t B,
     const BatchView& in, const BatchView& archives, uint32_t floatType, uint32_t maxSize,
     const uint32_t* hist_dev /*may be null*/, uint32_t* outSize_dev) {
   const uint32_t wordBytes = floatType ? floatWordBytes(floatType) : 1u;
@@ -652,7 +792,7 @@ int encodeCommon(
     // Float quirk kept from the reference (GpuFloatCompress.cuh:466-468): the
     // size in float WORDS is consumed as a BYTE count by the checksum.
     dim3 grid(gridX(maxSize, 64 * 1024, 64), B);
-    DGPU_LAUNCH("k_checksum", stream, k_checksum, grid, dim3(256), 0, stream, in, (const uint32_t*)nullptr, checksumTemp);
+    DGPU_LAUNCH("k_checksum", stream, k_checksum, grid, dim3(256), 0, stream, in, (const uint32_t*)nullptr, (const uint8_t*)nullptr, checksumTemp);
     DGPU_HIP(hipGetLastError());
   }
 
@@ -693,7 +833,7 @@ int encodeCommon(
     }
     HistFuse fuse;
     uint32_t* acc = nullptr;
-    int rc = arrivalCounters(stream, &fuse.arrive, &acc);
+    int rc = arrivalCounters(lease, &fuse.arrive, &acc);
     if (rc) return rc;
     fuse.acc = accumulate ? acc : nullptr;
     n.hist = histTemp;
@@ -768,7 +908,8 @@ int ansEncodeImpl(
   if (tempUsed) *tempUsed = 0;
   if (B == 0) return DGPU_OK;
 
-  TempArena arena(temp_dev, tempBytes, stream);
+  StreamLease streamLease(stream);
+  TempArena arena(temp_dev, tempBytes, streamLease);
   ParamLease lease;
   BatchView in, out;
   if (hp) {
@@ -782,7 +923,7 @@ int ansEncodeImpl(
     in = *strideIn;
     out = *strideOut;
   }
-  int rc = encodeCommon(arena, stream, P, useChecksum != 0, B, in, out, 0, maxSize, histogram_dev, outSize_dev);
+  int rc = encodeCommon(arena, streamLease, stream, P, useChecksum != 0, B, in, out, 0, maxSize, histogram_dev, outSize_dev);
   if (tempUsed) *tempUsed = arena.requested();
   return rc;
 }
@@ -797,7 +938,8 @@ int floatCompressImpl(
   if (tempUsed) *tempUsed = 0;
   if (B == 0) return DGPU_OK;
 
-  TempArena arena(temp_dev, tempBytes, stream);
+  StreamLease streamLease(stream);
+  TempArena arena(temp_dev, tempBytes, streamLease);
   ParamLease lease;
   const uint64_t *inP = nullptr, *outP = nullptr;
   const uint32_t* sz = nullptr;
@@ -807,7 +949,7 @@ int floatCompressImpl(
   BatchView out = viewPointers(outP, nullptr, 0);
 
   // No exponent plane in temp memory: the encoder splits the float words itself.
-  rc = encodeCommon(arena, stream, P, useChecksum != 0, B, in, out, ft, maxSize, nullptr, outSize_dev);
+  rc = encodeCommon(arena, streamLease, stream, P, useChecksum != 0, B, in, out, ft, maxSize, nullptr, outSize_dev);
   if (tempUsed) *tempUsed = arena.requested();
   return rc;
 }
@@ -846,7 +988,8 @@ int decodeImpl(
   if (errBatch) *errBatch = -1;
   if (B == 0) return DGPU_OK;
 
-  TempArena arena(temp_dev, tempBytes, stream);
+  StreamLease streamLease(stream);
+  TempArena arena(temp_dev, tempBytes, streamLease);
   ParamLease lease;
   BatchView in, out;
   if (hp) {
@@ -903,7 +1046,8 @@ int decodeImpl(
     DGPU_ALLOC(sums, uint32_t, arena, 2 * (size_t)B);
     DGPU_HIP(hipMemsetAsync(sums, 0, 2 * (size_t)B * 4, stream));
     dim3 grid(gridX(maxCapacity * (ft ? floatWordBytes(ft) : 1u), 64 * 1024, 64), B);
-    hipLaunchKernelGGL(k_checksum, grid, dim3(256), 0, stream, out, (const uint32_t*)sizesForChecksum, sums);
+    hipLaunchKernelGGL(k_checksum, grid, dim3(256), 0, stream, out, (const uint32_t*)sizesForChecksum,
+                       (const uint8_t*)successForChecksum, sums);
     DGPU_HIP(hipGetLastError());
     if (ft) {
       hipLaunchKernelGGL(k_float_info, dim3(divUp(B, 128)), dim3(128), 0, stream, in, B,
@@ -978,6 +1122,10 @@ uint32_t absentWorkgroupModulo() { return g_absentModulo.load(); }
 extern "C" {
 void dgpu_debug_set_absent_workgroups(uint32_t modulo) { g_absentModulo.store(modulo); }
 void dgpu_debug_set_param_cache(int on) { g_paramCacheEnabled.store(on != 0); }
+
+int dgpu_release_stream_state(void* stream) { return streamRegistry().release((hipStream_t)stream, false); }
+int dgpu_release_all_stream_state(void) { return streamRegistry().release(nullptr, true); }
+uint32_t dgpu_debug_stream_state_count(void) { return (uint32_t)streamRegistry().size(); }
 
 void dgpu_prof_enable(int on) {
   ProfState& p = prof();

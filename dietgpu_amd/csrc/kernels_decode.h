@@ -280,22 +280,63 @@ __global__ __launch_bounds__(kTileBlocks * 32u) void k_ans_decode(DecodeArgs a) 
 
   const uint8_t* archive = a.in.ptr(b);
   uint32_t floatSize = 0;
+  if (FT) {
+    // the float header locates the ANS archive: check it before following it
+    // (GpuFloatHeader::checkMagicAndVersion / getFloatType asserts, GpuFloatUtils.cuh:31-41, GpuFloatDecompress.cuh:332-382)
+    const FloatHeader fh = *(const FloatHeader*)archive;
+    const bool fhOk = fh.magicAndVersion == ((kFloatMagic << 16) | kFloatVersion) && (fh.options & 0xfu) == FT &&
+        fh.size <= a.out.size(b);
+    if (!fhOk) {  // uniform
+      if (tile == 0 && tid == 0) {
+        if (a.outSuccess) a.outSuccess[b] = 0;
+        if (a.outSize) a.outSize[b] = fh.size;
+      }
+      return;
+    }
+  }
   const uint8_t* ans = locateAns(archive, FT, &floatSize);
   const AnsHeader header = *(const AnsHeader*)ans;
   const uint32_t nb = header.numBlocks;
   const uint32_t total = header.totalUncompressedWords;
+  const uint32_t totalWords = header.totalCompressedWords;
 
   // Is there room for the output?  Capacity and size are in the API's units
-  // (bytes for raw ANS, float words for the float codec); GpuANSDecode.cuh:325-341
+  // (bytes for raw ANS, float words for the float codec); GpuANSDecode.cuh:325-341.
+  // The format invariants the reference only asserts (GpuANSDecode.cuh:323,448,
+  // GpuANSUtils.cuh:109-112) are CHECKED here: a corrupt or truncated archive is
+  // reported through outSuccess instead of being followed out of bounds.  Every
+  // quantity used for addressing below is bounded by the caller's capacity:
+  // total <= capacity, nb == ceil(total / 4096), block sizes as the format
+  // prescribes, block data inside [0, totalCompressedWords).
   bool success = a.out.size(b) >= total;
   success = success && header.magicAndVersion == ((kAnsMagic << 16) | kAnsVersion) &&
       (header.options & 0xfu) == (uint32_t)P;
   if (FT) success = success && floatSize == total;
-  if (tile == 0 && tid == 0) {
-    if (a.outSuccess) a.outSuccess[b] = success ? 1 : 0;
-    if (a.outSize) a.outSize[b] = total;
+  success = success && nb == divUp(total, kBlockSize);
+  if (!success) {  // uniform: nothing else of the archive is read
+    if (tile == 0 && tid == 0) {
+      if (a.outSuccess) a.outSuccess[b] = 0;
+      if (a.outSize) a.outSize[b] = total;
+    }
+    return;
   }
-  if (!success || tile * kTileBlocks >= nb) return;
+  if (tile * kTileBlocks >= nb && tile != 0) return;
+
+  const uint2* blockWords = (const uint2*)(ans + ansBlockWordsOffset(nb));
+  // {uncompressed words << 16 | compressed words, start} of block i must be what an
+  // encoder can produce: the size the format prescribes, 16-byte aligned data inside the archive
+  auto blockOk = [&](uint32_t i, uint2 bw) -> bool {
+    const uint32_t want = (i + 1u < nb) ? kBlockSize : total - i * kBlockSize;
+    const uint32_t words = bw.x & 0xffffu;
+    return (bw.x >> 16) == want && (bw.y & (kBlockAlignWords - 1u)) == 0u &&
+        (uint64_t)bw.y + roundUp(words, kBlockAlignWords) <= (uint64_t)totalWords;
+  };
+  // tile 0 vouches for the whole element (it alone writes outSuccess); its loads are
+  // issued here and checked after the LUT build
+  bool allBlocksOk = true;
+  if (tile == 0) {
+    for (uint32_t i = tid; i < nb; i += kDecThreads) allBlocksOk = allBlocksOk && blockOk(i, blockWords[i]);
+  }
 
   // Decode LUT, built by the workgroup itself from the archive's pdf table (no
   // separate table kernel / LUT round trip through HBM):
@@ -304,18 +345,38 @@ __global__ __launch_bounds__(kTileBlocks * 32u) void k_ans_decode(DecodeArgs a) 
   // that v_mad_u32_u24 can take word 0 directly: its low 24 bits are the pdf).
   // Wave 0 scans the 256 pdfs on its own (4 per lane), so one barrier suffices;
   // the cdf/pdf scratch lives in the ring area, which is not in use yet.
+  uint32_t* sCdf = (uint32_t*)smem;
+  uint32_t* sPdf = sCdf + kNumSymbols;
+  uint32_t* sPdfSum = sPdf + kNumSymbols;
+  uint32_t* sWaveBad = sPdfSum + 1;  // one flag per wave (<= 8); no static LDS in this kernel (ring alignment)
   {
-    uint32_t* sCdf = (uint32_t*)smem;
-    uint32_t* sPdf = sCdf + kNumSymbols;
+    {
+      const bool waveBad = __ballot(!allBlocksOk) != 0ull;
+      if (lane == 0u) sWaveBad[wave] = waveBad ? 1u : 0u;
+    }
     if (wave == 0) {
       const uint2 raw = ((const uint2*)(ans + sizeof(AnsHeader)))[lane];  // pdf[4 lane .. 4 lane + 3]
       const uint32_t p0 = raw.x & 0xffffu, p1 = raw.x >> 16, p2 = raw.y & 0xffffu, p3 = raw.y >> 16;
       const uint32_t mine = p0 + p1 + p2 + p3;
-      const uint32_t base = waveInclusiveScan(mine, lane) - mine;
+      const uint32_t incl = waveInclusiveScan(mine, lane);
+      const uint32_t base = incl - mine;
       ((uint4*)sCdf)[lane] = make_uint4(base, base + p0, base + p0 + p1, base + p0 + p1 + p2);
       ((uint4*)sPdf)[lane] = make_uint4(p0, p1, p2, p3);
+      if (lane == 63u) *sPdfSum = incl;
     }
     __syncthreads();
+    // the reduction of tile 0's block checks
+    uint32_t anyBad = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kDecThreads / 64u; ++w) anyBad |= sWaveBad[w];
+    const bool blocksOk = anyBad == 0u;
+    // the probabilities of a non-empty element sum to 2^P (GpuANSStatistics.cuh:256-316)
+    const bool pdfOk = nb == 0u || *sPdfSum == (1u << P);
+    if (tile == 0 && tid == 0) {
+      if (a.outSuccess) a.outSuccess[b] = (blocksOk && pdfOk) ? 1 : 0;
+      if (a.outSize) a.outSize[b] = total;
+    }
+    if (!pdfOk || tile * kTileBlocks >= nb) return;  // uniform
     for (uint32_t x = tid; x < (1u << P); x += kDecThreads) {
       // last symbol s with cdf[s] <= x (zero-pdf symbols share the cdf of their
       // successor and are skipped by taking the last one)
@@ -332,16 +393,19 @@ __global__ __launch_bounds__(kTileBlocks * 32u) void k_ans_decode(DecodeArgs a) 
   }
 
   const uint32_t block = tile * kTileBlocks + hw;
-  const bool haveBlock = block < nb;
+  bool haveBlock = block < nb;
 
   uint32_t state = 0, n = 0, numWords = 0, start = 0;
   if (haveBlock) {
-    state = ((const uint32_t*)(ans + ansStatesOffset()))[block * 32u + hl];
-    const uint2 bw = ((const uint2*)(ans + ansBlockWordsOffset(nb)))[block];
-    n = bw.x >> 16;
-    n = n < kBlockSize ? n : kBlockSize;  // malformed archive guard
-    numWords = bw.x & 0xffffu;
-    start = bw.y;
+    const uint2 bw = blockWords[block];
+    if (blockOk(block, bw)) {
+      state = ((const uint32_t*)(ans + ansStatesOffset()))[block * 32u + hl];
+      n = bw.x >> 16;
+      numWords = bw.x & 0xffffu;
+      start = bw.y;
+    } else {
+      haveBlock = false;  // malformed block: neither read nor written (tile 0 has reported the element)
+    }
   }
   const uint8_t* gwords = ans + ansOverhead(nb) + 2u * (size_t)start;
   __syncthreads();  // LUT visible to every wave, scratch free (each half-wave's ring is private to its wave)

@@ -429,12 +429,16 @@ __global__ __launch_bounds__(256) void k_histogram(BatchView in, uint32_t* __res
 // `floatWords` != 0 reproduces the float-path quirk: the provider's size is in
 // float words but is consumed as a byte count, so only the first `size` bytes
 // are covered (GpuFloatCompress.cuh:466-468).  `sizesOverride` (nullable) lets
-// the decode side checksum exactly the decoded size.
+// the decode side checksum exactly the decoded size; `onlyIf` (nullable) skips
+// elements whose decode failed (their output buffer may be smaller than the size
+// recorded in the archive: nothing of it may be read).
 __global__ __launch_bounds__(256) void k_checksum(
-    BatchView in, const uint32_t* __restrict__ sizesOverride, uint32_t* __restrict__ out) {
+    BatchView in, const uint32_t* __restrict__ sizesOverride, const uint8_t* __restrict__ onlyIf,
+    uint32_t* __restrict__ out) {
   __shared__ uint32_t partial[4];
   const uint32_t tid = threadIdx.x;
   const uint32_t b = blockIdx.y;
+  if (onlyIf && !onlyIf[b]) return;  // uniform
   const uint8_t* p = in.ptr(b);
   uint32_t size = sizesOverride ? sizesOverride[b] : in.size(b);
 

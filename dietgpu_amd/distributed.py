@@ -47,6 +47,16 @@ def gather_sizes(local_sizes, num_elements):
     return torch.cat([o[: e - s] for o, (s, e) in zip(out, counts)])
 
 
+def gather_scalars(value, device):
+    """Every rank's float, in rank order, on every rank."""
+    if dist.get_backend() != "nccl":
+        device = "cpu"
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def max_over_ranks(seconds, device):
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -222,6 +222,19 @@ int dgpu_ans_calc_weights(
     uint32_t* table_dev,
     void* stream);
 
+/* ---- library-owned device state (no upstream equivalent) -------------------- */
+/* The library keeps a little device memory per (device, stream) it has been used
+ * on: the temp-memory overflow slab (what StackDeviceMemory.cpp:119-139 would
+ * cudaMalloc/cudaFree per call) and the zero-at-rest hand-off counters of the
+ * histogram pass.  It is bounded (the least recently used idle states are dropped
+ * beyond 32 streams), and can be given back explicitly: synchronises the device,
+ * frees the memory kept for `stream` on the current device (or for every stream),
+ * returns the number of states released.  Call before destroying a stream. */
+int dgpu_release_stream_state(void* stream);
+int dgpu_release_all_stream_state(void);
+/* Test hook: number of (device, stream) states currently kept. */
+uint32_t dgpu_debug_stream_state_count(void);
+
 /* ---- instrumentation (no upstream equivalent) ------------------------------ */
 /* Per-kernel timing with HIP events recorded on the launch stream; used by
  * bench.py for the roofline figure.  Off by default. */

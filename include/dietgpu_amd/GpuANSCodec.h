@@ -1,8 +1,9 @@
 // dietgpu::ansEncodeBatch* / ansDecodeBatch* / ansGetCompressedInfo* with the
 // reference's C++ signatures (dietgpu/ans/GpuANSCodec.h:16-341, cudaStream_t ->
 // hipStream_t), implemented inline on top of the C ABI of ../dietgpu_amd.h.
-// Temp memory is reserved from the caller's StackDeviceMemory for the duration
-// of the call and handed to the C ABI as a raw region.
+// Temp memory: the free part of the caller's StackDeviceMemory is handed to the
+// C ABI as a raw region for the duration of the call; the bytes the call used are
+// recorded in the stack's high-water mark.
 #pragma once
 
 #include <sstream>
@@ -51,11 +52,19 @@ inline ANSDecodeStatus toStatus(int rc, int32_t errBatch) {
   }
   return s;
 }
+// The free part of the caller's stack (at most `want` bytes, the call's upper
+// bound) is lent to the C ABI for the duration of the call; what the call really
+// needed (`used`, reported by the C ABI) is what counts towards
+// getMaxMemoryUsage(), as upstream where every temporary is alloc()ed one by one.
 struct TempRegion {
-  TempRegion(StackDeviceMemory& res, hipStream_t stream, size_t bytes)
-      : mem(res.alloc<uint8_t>(stream, bytes)), bytes(bytes) {}
-  GpuMemoryReservation<uint8_t> mem;
-  size_t bytes;
+  TempRegion(StackDeviceMemory& r, hipStream_t, size_t want) : res(r), ptr(r.lendFree(want, &bytes)) {}
+  ~TempRegion() { res.noteUsage(used); }
+  TempRegion(const TempRegion&) = delete;
+  TempRegion& operator=(const TempRegion&) = delete;
+  StackDeviceMemory& res;
+  size_t bytes = 0;
+  void* ptr;
+  size_t used = 0;
 };
 }  // namespace detail
 
@@ -64,7 +73,7 @@ inline void ansEncodeBatchStride(
     uint32_t inPerBatchSize, uint32_t inPerBatchStride, const uint32_t* histogram_dev, void* out_dev,
     uint32_t outPerBatchStride, uint32_t* outBatchSize_dev, hipStream_t stream) {
   detail::TempRegion t(res, stream, dgpu_ans_encode_temp_bytes(numInBatch, inPerBatchSize));
-  detail::checkRc(dgpu_ans_encode_batch_stride(t.mem.data(), t.bytes, nullptr, config.probBits, config.useChecksum,
+  detail::checkRc(dgpu_ans_encode_batch_stride(t.ptr, t.bytes, &t.used, config.probBits, config.useChecksum,
                                                numInBatch, in_dev, inPerBatchSize, inPerBatchStride, histogram_dev,
                                                out_dev, outPerBatchStride, outBatchSize_dev, stream),
                   "ansEncodeBatchStride");
@@ -76,7 +85,7 @@ inline void ansEncodeBatchPointer(
   uint32_t maxSize = 0;
   for (uint32_t i = 0; i < numInBatch; ++i) maxSize = std::max(maxSize, inSize[i]);
   detail::TempRegion t(res, stream, dgpu_ans_encode_temp_bytes(numInBatch, maxSize));
-  detail::checkRc(dgpu_ans_encode_batch_pointer(t.mem.data(), t.bytes, nullptr, config.probBits, config.useChecksum,
+  detail::checkRc(dgpu_ans_encode_batch_pointer(t.ptr, t.bytes, &t.used, config.probBits, config.useChecksum,
                                                 numInBatch, in, inSize, histogram_dev, out, outSize_dev, stream),
                   "ansEncodeBatchPointer");
 }
@@ -88,7 +97,7 @@ inline void ansEncodeBatchSplitSize(
   uint32_t maxSize = 0;
   for (uint32_t i = 0; i < numInBatch; ++i) maxSize = std::max(maxSize, inSplitSizes[i]);
   detail::TempRegion t(res, stream, dgpu_ans_encode_temp_bytes(numInBatch, maxSize));
-  detail::checkRc(dgpu_ans_encode_batch_split_size(t.mem.data(), t.bytes, nullptr, config.probBits, config.useChecksum,
+  detail::checkRc(dgpu_ans_encode_batch_split_size(t.ptr, t.bytes, &t.used, config.probBits, config.useChecksum,
                                                    numInBatch, in_dev, inSplitSizes, histogram_dev, out_dev, outStride,
                                                    outSize_dev, stream),
                   "ansEncodeBatchSplitSize");
@@ -100,7 +109,7 @@ inline ANSDecodeStatus ansDecodeBatchStride(
     uint8_t* outSuccess_dev, uint32_t* outSize_dev, hipStream_t stream) {
   detail::TempRegion t(res, stream, dgpu_ans_decode_temp_bytes(numInBatch, outPerBatchCapacity, config.probBits));
   int32_t err = -1;
-  int rc = dgpu_ans_decode_batch_stride(t.mem.data(), t.bytes, nullptr, config.probBits, config.useChecksum, numInBatch,
+  int rc = dgpu_ans_decode_batch_stride(t.ptr, t.bytes, &t.used, config.probBits, config.useChecksum, numInBatch,
                                         in_dev, inPerBatchStride, out_dev, outPerBatchStride, outPerBatchCapacity,
                                         outSuccess_dev, outSize_dev, stream, &err);
   detail::checkRc(rc, "ansDecodeBatchStride");
@@ -114,7 +123,7 @@ inline ANSDecodeStatus ansDecodeBatchPointer(
   for (uint32_t i = 0; i < numInBatch; ++i) maxCap = std::max(maxCap, outCapacity[i]);
   detail::TempRegion t(res, stream, dgpu_ans_decode_temp_bytes(numInBatch, maxCap, config.probBits));
   int32_t err = -1;
-  int rc = dgpu_ans_decode_batch_pointer(t.mem.data(), t.bytes, nullptr, config.probBits, config.useChecksum,
+  int rc = dgpu_ans_decode_batch_pointer(t.ptr, t.bytes, &t.used, config.probBits, config.useChecksum,
                                          numInBatch, in, out, outCapacity, outSuccess_dev, outSize_dev, stream, &err);
   detail::checkRc(rc, "ansDecodeBatchPointer");
   return detail::toStatus(rc, err);
@@ -127,7 +136,7 @@ inline ANSDecodeStatus ansDecodeBatchSplitSize(
   for (uint32_t i = 0; i < numInBatch; ++i) maxCap = std::max(maxCap, outSplitSizes[i]);
   detail::TempRegion t(res, stream, dgpu_ans_decode_temp_bytes(numInBatch, maxCap, config.probBits));
   int32_t err = -1;
-  int rc = dgpu_ans_decode_batch_split_size(t.mem.data(), t.bytes, nullptr, config.probBits, config.useChecksum,
+  int rc = dgpu_ans_decode_batch_split_size(t.ptr, t.bytes, &t.used, config.probBits, config.useChecksum,
                                             numInBatch, in, out_dev, outSplitSizes, outSuccess_dev, outSize_dev,
                                             stream, &err);
   detail::checkRc(rc, "ansDecodeBatchSplitSize");
@@ -138,7 +147,7 @@ inline void ansGetCompressedInfo(
     StackDeviceMemory& res, const void** in, uint32_t numInBatch, uint32_t* outSizes_dev,
     uint32_t* outChecksum_dev, hipStream_t stream) {
   detail::TempRegion t(res, stream, (size_t)numInBatch * 8 + 256);
-  detail::checkRc(dgpu_ans_get_compressed_info(t.mem.data(), t.bytes, in, numInBatch, outSizes_dev, outChecksum_dev, stream),
+  detail::checkRc(dgpu_ans_get_compressed_info(t.ptr, t.bytes, in, numInBatch, outSizes_dev, outChecksum_dev, stream),
                   "ansGetCompressedInfo");
 }
 

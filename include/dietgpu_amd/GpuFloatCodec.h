@@ -50,7 +50,7 @@ inline void floatCompress(
   uint32_t maxSize = 0;
   for (uint32_t i = 0; i < numInBatch; ++i) maxSize = std::max(maxSize, inSize[i]);
   detail::TempRegion t(res, stream, dgpu_float_compress_temp_bytes((uint32_t)config.floatType, numInBatch, maxSize));
-  detail::checkRc(dgpu_float_compress(t.mem.data(), t.bytes, nullptr, (uint32_t)config.floatType,
+  detail::checkRc(dgpu_float_compress(t.ptr, t.bytes, &t.used, (uint32_t)config.floatType,
                                       config.ansConfig.probBits, config.useChecksum, numInBatch, in, inSize, out,
                                       outSize_dev, stream),
                   "floatCompress");
@@ -62,7 +62,7 @@ inline void floatCompressSplitSize(
   uint32_t maxSize = 0;
   for (uint32_t i = 0; i < numInBatch; ++i) maxSize = std::max(maxSize, inSplitSizes[i]);
   detail::TempRegion t(res, stream, dgpu_float_compress_temp_bytes((uint32_t)config.floatType, numInBatch, maxSize));
-  detail::checkRc(dgpu_float_compress_split_size(t.mem.data(), t.bytes, nullptr, (uint32_t)config.floatType,
+  detail::checkRc(dgpu_float_compress_split_size(t.ptr, t.bytes, &t.used, (uint32_t)config.floatType,
                                                  config.ansConfig.probBits, config.useChecksum, numInBatch, in_dev,
                                                  inSplitSizes, out_dev, outStride, outSize_dev, stream),
                   "floatCompressSplitSize");
@@ -76,7 +76,7 @@ inline FloatDecompressStatus floatDecompress(
   detail::TempRegion t(res, stream, dgpu_float_decompress_temp_bytes((uint32_t)config.floatType, numInBatch, maxCap,
                                                                      config.ansConfig.probBits));
   int32_t err = -1;
-  int rc = dgpu_float_decompress(t.mem.data(), t.bytes, nullptr, (uint32_t)config.floatType, config.ansConfig.probBits,
+  int rc = dgpu_float_decompress(t.ptr, t.bytes, &t.used, (uint32_t)config.floatType, config.ansConfig.probBits,
                                  config.useChecksum, numInBatch, in, out, outCapacity, outSuccess_dev, outSize_dev,
                                  stream, &err);
   detail::checkRc(rc, "floatDecompress");
@@ -91,7 +91,7 @@ inline FloatDecompressStatus floatDecompressSplitSize(
   detail::TempRegion t(res, stream, dgpu_float_decompress_temp_bytes((uint32_t)config.floatType, numInBatch, maxCap,
                                                                      config.ansConfig.probBits));
   int32_t err = -1;
-  int rc = dgpu_float_decompress_split_size(t.mem.data(), t.bytes, nullptr, (uint32_t)config.floatType,
+  int rc = dgpu_float_decompress_split_size(t.ptr, t.bytes, &t.used, (uint32_t)config.floatType,
                                             config.ansConfig.probBits, config.useChecksum, numInBatch, in, out_dev,
                                             outSplitSizes, outSuccess_dev, outSize_dev, stream, &err);
   detail::checkRc(rc, "floatDecompressSplitSize");
@@ -102,7 +102,7 @@ inline void floatGetCompressedInfo(
     StackDeviceMemory& res, const void** in, uint32_t numInBatch, uint32_t* outSizes_dev, uint32_t* outTypes_dev,
     uint32_t* outChecksum_dev, hipStream_t stream) {
   detail::TempRegion t(res, stream, (size_t)numInBatch * 8 + 256);
-  detail::checkRc(dgpu_float_get_compressed_info(t.mem.data(), t.bytes, in, numInBatch, outSizes_dev, outTypes_dev,
+  detail::checkRc(dgpu_float_get_compressed_info(t.ptr, t.bytes, in, numInBatch, outSizes_dev, outTypes_dev,
                                                  outChecksum_dev, stream),
                   "floatGetCompressedInfo");
 }

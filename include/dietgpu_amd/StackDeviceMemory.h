@@ -171,8 +171,15 @@ class StackDeviceMemory {
   size_t getSizeTotal() const { return size_; }
   size_t getMaxMemoryUsage() const { return maxSeen_; }
   void resetMaxMemoryUsage() { maxSeen_ = 0; }
-  // used by the codec wrappers to report what the C ABI needed
-  void noteUsage(size_t bytes) { maxSeen_ = std::max(maxSeen_, (size_t)(head_ - start_) + bytes); }
+  // Used by the codec wrappers: the unused part of the stack (at most `want` bytes) as a raw
+  // region for ONE call -- nothing is reserved, the caller must not alloc() until that call has
+  // been enqueued (the upstream codec functions hold their reservations the same way) -- and
+  // the bytes the call turned out to need, for the high-water mark.
+  void* lendFree(size_t want, size_t* got) {
+    *got = std::min(want, getSizeAvailable());
+    return *got ? (void*)head_ : nullptr;
+  }
+  void noteUsage(size_t bytes) { maxSeen_ = std::max(maxSeen_, (size_t)(head_ - start_) + overflowSize_ + bytes); }
 
  private:
   int device_;

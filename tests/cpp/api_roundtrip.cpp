@@ -71,7 +71,20 @@ int main() {
     EXPECT(hs[i] % 16 == 0);
     EXPECT(back == data[i]);
   }
+  // the high-water mark is what the call needed, not the upper bound it was offered
   EXPECT(res.getMaxMemoryUsage() > 0);
+  EXPECT(res.getMaxMemoryUsage() <= dgpu_ans_encode_temp_bytes(3, 10013));
+  EXPECT(res.getSizeAvailable() == res.getSizeTotal());  // nothing stays reserved
+  {
+    // a stack that is too small: the call still succeeds (library-owned overflow memory, with a warning)
+    auto tiny = makeStackMemory(1024);
+    ansEncodeBatchPointer(tiny, cfg, 3, in.data(), sizes.data(), nullptr, comp.data(), outSize_dev, stream);
+    uint32_t hs2[3];
+    HIP(hipMemcpyAsync(hs2, outSize_dev, 12, hipMemcpyDeviceToHost, stream));
+    HIP(hipStreamSynchronize(stream));
+    for (int i = 0; i < 3; ++i) EXPECT(hs2[i] == hs[i]);
+    EXPECT(tiny.getMaxMemoryUsage() > 1024);
+  }
 
   // --- float codec, bf16, batch of 2 (FloatTest.cu: Batch) ---
   std::normal_distribution<float> nd;

@@ -622,25 +622,32 @@ def test_float_capacity_and_checksum(dg):
 
 
 # ------------------------------------------------- BASELINE configs, full size
-def _check_rows_against_oracle(comp, sizes, rows, encode):
-    hs = sizes.cpu().numpy()
-    for i in rows:
-        want = encode(i)
-        got = comp[i, : hs[i]].cpu().numpy()
-        assert hs[i] == want.size and (got == want).all(), f"row {i}"
+import os
+
+_THREADS = os.cpu_count() or 8
+
+
+def _check_all_rows(comp, sizes, want_rows, want_sizes):
+    """Every row of the batch, byte for byte (FloatTest.cu:286-298 LargeBatch compares every element)."""
+    hs = sizes.cpu().numpy().astype(np.int64)
+    assert (hs == want_sizes.astype(np.int64)).all(), np.nonzero(hs != want_sizes)[0][:8]
+    width = int(hs.max())
+    got = comp[:, :width].cpu().numpy()
+    mask = np.arange(width)[None, :] < hs[:, None]
+    diff = (got != want_rows[:, :width]) & mask
+    assert not diff.any(), f"rows {np.nonzero(diff.any(axis=1))[0][:8]} differ from the oracle"
 
 
 def test_baseline_config2_zipf_bytes(dg):
+    # SURVEY.md section 8(d): 256 independent rows, default_rng(1234 + b)
     B, n = 256, 1 << 20
-    x = refgen.zipf_bytes(8, n)  # 8 distinct rows, tiled to 256
-    xs = np.tile(x, (B // 8, 1))
+    xs = refgen.zipf_bytes(B, n)
     t = torch.from_numpy(xs).to(DEV)
     ts = list(t.unbind(0))
     comp, sizes, _ = dg.compress_data(False, ts)
-    _check_rows_against_oracle(comp, sizes, [0, 3, 255], lambda i: O.ans_encode(xs[i], 10))
-    hs = sizes.cpu().numpy()
-    assert (hs[:8] == hs[8:16]).all()
-    ratio = hs.sum() / xs.size
+    want, wsz = O.ans_encode_batch(xs, 10, threads=_THREADS)
+    _check_all_rows(comp, sizes, want, wsz)
+    ratio = sizes.cpu().numpy().sum() / xs.size
     assert abs(ratio - 0.695) < 0.02
     outs = [torch.empty((n,), dtype=torch.uint8, device=DEV) for _ in range(B)]
     dg.decompress_data(False, list(comp.unbind(0)), outs)
@@ -653,7 +660,8 @@ def test_baseline_config3_bf16(dg):
     t = torch.from_numpy(w.view(np.int16)).to(DEV).view(torch.bfloat16)
     ts = list(t.unbind(0))
     comp, sizes, _ = dg.compress_data(True, ts)
-    _check_rows_against_oracle(comp, sizes, [0, 100, 255], lambda i: O.float_compress(O.BFLOAT16, w[i], 10))
+    want, wsz = O.float_compress_batch(O.BFLOAT16, w, 10, threads=_THREADS)
+    _check_all_rows(comp, sizes, want, wsz)
     ratio = sizes.cpu().numpy().sum() / (w.size * 2)
     assert abs(ratio - 0.673) < 0.01
     outs = [torch.empty((n,), dtype=torch.bfloat16, device=DEV) for _ in range(B)]
@@ -669,10 +677,245 @@ def test_baseline_config4_sparse_fp16_p11(dg):
     t = torch.from_numpy(w.view(np.int16)).to(DEV).view(torch.float16)
     ts = list(t.unbind(0))
     comp, sizes, _ = dg.compress_data(True, ts, prob_bits=11)
-    _check_rows_against_oracle(comp, sizes, [0, 77], lambda i: O.float_compress(O.FLOAT16, w[i], 11))
+    want, wsz = O.float_compress_batch(O.FLOAT16, w, 11, threads=_THREADS)
+    _check_all_rows(comp, sizes, want, wsz)
     outs = [torch.empty((n,), dtype=torch.float16, device=DEV) for _ in range(B)]
     dg.decompress_data(True, list(comp.unbind(0)), outs, prob_bits=11)
     assert torch.equal(torch.stack(outs).view(torch.int16), t.view(torch.int16))
+
+
+def test_baseline_config5_shard_of_one_rank(dg):
+    # BASELINE config 5 = 2048 x 1 MiB bf16 over 8 ranks: rank g codes elements [256 g, 256 g + 256)
+    # generated with seed 1234 + g.  One GPU here: rank 3's shard, all rows.
+    from dietgpu_amd.distributed import shard_range
+
+    assert shard_range(2048, 3, 8) == (768, 1024)
+    B, n = 256, 512 * 1024
+    w = refgen.normal_bf16(B, n, seed=1234 + 3)
+    t = torch.from_numpy(w.view(np.int16)).to(DEV).view(torch.bfloat16)
+    comp, sizes, _ = dg.compress_data(True, list(t.unbind(0)))
+    want, wsz = O.float_compress_batch(O.BFLOAT16, w, 10, threads=_THREADS)
+    _check_all_rows(comp, sizes, want, wsz)
+
+
+# ------------------------------------------ multi-window look-back (> 64 tiles per element)
+# The ordered compaction replaces BatchPrefixSum.cuh:33-194, whose own test goes to 512 x 512
+# entries (BatchPrefixSumTest.cu:85-127).  One look-back step covers 64 predecessor tiles; elements
+# of 65, 129 and >= 1025 tiles need 2, 3 and 17 steps.  Archives are compared with the oracle byte
+# for byte (a round trip alone would not notice a gap or a wrong start offset), also with part of
+# the workgroups starting late.
+_TILE = 8 * 4096
+
+
+@pytest.mark.parametrize("tiles,absent", [(65, 0), (129, 0), (129, 3), (1025, 0), (1027, 7)])
+def test_lookback_windows_raw(dg, tiles, absent):
+    rng = np.random.default_rng(tiles)
+    n = tiles * _TILE - 1234  # last tile partial
+    # skewed bytes whose statistics drift along the element: block sizes vary from tile to tile
+    x = (rng.exponential(12.0 + 30.0 * np.linspace(0, 1, n)) % 256).astype(np.uint8)
+    small = rng.integers(0, 50, 3 * _TILE + 5, dtype=np.uint8)
+    L = dg.lib()
+    L.dgpu_debug_set_absent_workgroups(absent)
+    try:
+        got = gpu_ans_encode(dg, [x, small], 10)
+    finally:
+        L.dgpu_debug_set_absent_workgroups(0)
+    for data, g in zip((x, small), got):
+        want = O.ans_encode(data, 10)
+        assert g.size == want.size
+        bad = np.nonzero(g != want)[0]
+        assert bad.size == 0, f"first differing byte {bad[:4]} of {want.size}"
+    outs, status, osz = gpu_ans_decode(dg, got, [n, small.size], 10)
+    assert status.all() and (outs[0] == x).all() and (outs[1] == small).all()
+
+
+@pytest.mark.parametrize("absent", [0, 2])
+def test_lookback_windows_bf16_40m(dg, absent):
+    n = 40 * 1000 * 1000 + 7  # 1221 tiles
+    rng = np.random.default_rng(40)
+    f = rng.standard_normal(n, dtype=np.float32) * np.exp(rng.standard_normal(n, dtype=np.float32))
+    w = refgen.f32_to_bf16_rne(f)
+    t = words_to_tensor(O.BFLOAT16, w)
+    L = dg.lib()
+    L.dgpu_debug_set_absent_workgroups(absent)
+    try:
+        comp, sizes, _ = dg.compress_data(True, [t])
+    finally:
+        L.dgpu_debug_set_absent_workgroups(0)
+    want = O.float_compress(O.BFLOAT16, w, 10)
+    assert int(sizes[0]) == want.size
+    got = comp[0, : want.size].cpu().numpy()
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, f"first differing byte {bad[:4]} of {want.size}"
+    out = torch.empty_like(t)
+    dg.decompress_data(True, [comp[0, : want.size]], [out])
+    assert torch.equal(out.view(torch.int16), t.view(torch.int16))
+
+
+# ------------------------------------------------------------ malformed archives
+def _decode_status(dg, as_float, arch_np, out_like, prob_bits=10):
+    arch = torch.from_numpy(arch_np.copy()).to(DEV)
+    out = torch.full_like(out_like, 0)
+    status = torch.full((1,), 7, dtype=torch.uint8, device=DEV)
+    osz = torch.zeros((1,), dtype=torch.int32, device=DEV)
+    dg.decompress_data(as_float, [arch], [out], False, None, status, osz, prob_bits=prob_bits)
+    torch.cuda.synchronize()
+    return int(status.item()), out
+
+
+def test_decoder_rejects_malformed_ans_archives(dg):
+    # The reference guards the format with device asserts (GpuANSDecode.cuh:323,448,
+    # GpuANSUtils.cuh:109-112), compiled out in release builds.  Here a corrupt header, block
+    # table or pdf table is reported through outSuccess and nothing is decoded from it.
+    x = refgen.generate_symbols(5 * 4096 + 100, 20.0)
+    good = O.ans_encode(x, 10)
+    ref = torch.from_numpy(x).to(DEV)
+    st, out = _decode_status(dg, False, good, ref)
+    assert st == 1 and torch.equal(out, ref)
+    nb = 6
+    bw0 = 32 + 512 + 128 * nb  # blockWords table
+
+    def u32(a, off):
+        return a[off : off + 4].view(np.uint32)
+
+    cases = []
+    for name, off, val in [
+        ("magic", 0, 0xd00d0002), ("numBlocks+1", 4, nb + 1), ("numBlocks-1", 4, nb - 1), ("numBlocks huge", 4, 1 << 30),
+        ("total-1", 8, x.size - 1), ("probBits", 16, 11),
+        ("totalCompressedWords small", 12, 8),
+        ("block0 uncompressed size", bw0, (4095 << 16) | int(u32(good, bw0)[0] & 0xffff)),
+        ("block2 start past the end", bw0 + 2 * 8 + 4, int(u32(good, 12)[0])),
+        ("block3 start unaligned", bw0 + 3 * 8 + 4, int(u32(good, bw0 + 3 * 8 + 4)[0]) + 3),
+        ("last block size", bw0 + 5 * 8, (101 << 16) | int(u32(good, bw0 + 5 * 8)[0] & 0xffff)),
+    ]:
+        bad = good.copy()
+        u32(bad, off)[0] = val
+        cases.append((name, bad))
+    bad = good.copy()
+    bad[32:34].view(np.uint16)[0] += 1  # pdf no longer sums to 2^probBits
+    cases.append(("pdf sum", bad))
+    for name, bad in cases:
+        st, out = _decode_status(dg, False, bad, ref)
+        assert st == 0, name
+    # a corrupt element does not disturb its neighbours in the batch
+    archs = [torch.from_numpy(cases[3][1].copy()).to(DEV), torch.from_numpy(good.copy()).to(DEV)]
+    outs = [torch.zeros_like(ref), torch.zeros_like(ref)]
+    status = torch.zeros((2,), dtype=torch.uint8, device=DEV)
+    dg.decompress_data(False, archs, outs, False, None, status, None)
+    assert status.cpu().tolist() == [0, 1] and torch.equal(outs[1], ref)
+
+
+def test_decoder_rejects_malformed_float_archives(dg):
+    w = refgen.generate_floats(O.BFLOAT16, 3 * 4096 + 77)
+    good = O.float_compress(O.BFLOAT16, w, 10)
+    ref = words_to_tensor(O.BFLOAT16, w)
+    st, out = _decode_status(dg, True, good, ref)
+    assert st == 1 and torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    for name, off, val in [("float magic", 0, 0xf00f0003), ("float size larger", 4, w.size + 16),
+                           ("float size huge", 4, 0xfffffff0), ("float type", 8, O.FLOAT16),
+                           ("float size smaller", 4, w.size - 16)]:
+        bad = good.copy()
+        bad[off : off + 4].view(np.uint32)[0] = val
+        st, _ = _decode_status(dg, True, bad, ref)
+        assert st == 0, name
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_decoder_fuzzed_headers_do_not_fault(dg, seed):
+    # random bit flips anywhere in the header / pdf / state / block tables: the decoder either
+    # decodes something (flips in states or pdfs that keep the invariants) or reports failure, and
+    # the process survives; capacity-bounded output is the only memory written
+    rng = np.random.default_rng(1000 + seed)
+    x = refgen.generate_symbols(9 * 4096 + 11, 50.0)
+    good = O.ans_encode(x, 10)
+    overhead = 32 + 512 + 128 * 10 + 8 * 10
+    ref = torch.from_numpy(x).to(DEV)
+    guard = torch.full((x.size + 4096,), 0xAB, dtype=torch.uint8, device=DEV)
+    for _ in range(60):
+        bad = good.copy()
+        for _k in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(0, overhead))
+            bad[pos] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        arch = torch.from_numpy(bad).to(DEV)
+        out = guard[: x.size]
+        status = torch.zeros((1,), dtype=torch.uint8, device=DEV)
+        dg.decompress_data(False, [arch], [out], False, None, status, None)
+        torch.cuda.synchronize()
+        assert (guard[x.size :] == 0xAB).all()  # nothing written past the capacity
+
+
+# ------------------------------------------------- library-owned state (overflow slab, streams)
+def test_overflow_slab_growth_inside_one_call(dg):
+    # No temp memory, checksum on: a small call warms the slab, the next one is large enough to
+    # outgrow it twice inside ONE call.  Allocations handed out before the growth (checksums,
+    # tables) must stay valid until the kernels that read them have run.
+    L = dg.lib()
+    L.dgpu_release_all_stream_state()
+    small = [to_dev_bytes(refgen.generate_symbols(3000 + i, 20.0)) for i in range(2)]
+    dg.compress_data(False, small, True, None)
+    rng = np.random.default_rng(9)
+    for B, n in ((3000, 700), (20000, 300), (64, 3 << 20)):
+        base = rng.integers(0, 60, n * 4 + 4096, dtype=np.uint8)
+        buf = torch.from_numpy(base).to(DEV)
+        offs = (rng.integers(0, n * 3, B) // 4) * 4
+        lens = rng.integers(max(n // 2, 1), n, B)
+        ts = [buf[int(o) : int(o) + int(m)] for o, m in zip(offs, lens)]
+        comp, sizes, _ = dg.compress_data(False, ts, True, None)
+        hs, hc = sizes.cpu().numpy(), comp.cpu().numpy()
+        step = max(B // 40, 1)
+        for i in list(range(0, B, step)) + [B - 1]:
+            want = O.ans_encode(base[int(offs[i]) : int(offs[i]) + int(lens[i])], 10, use_checksum=True)
+            assert hs[i] == want.size and (hc[i, : hs[i]] == want).all(), (B, i)
+        outs = [torch.empty((int(m),), dtype=torch.uint8, device=DEV) for m in lens]
+        dg.decompress_data(False, [comp[i] for i in range(B)], outs, True, None)
+        for i in range(0, B, step):
+            assert torch.equal(outs[i], ts[i])
+
+
+def test_stream_state_is_bounded_and_releasable(dg):
+    L = dg.lib()
+    L.dgpu_release_all_stream_state()
+    assert L.dgpu_debug_stream_state_count() == 0
+    w = refgen.generate_floats(O.BFLOAT16, 4096 * 8 + 3)
+    want = O.float_compress(O.BFLOAT16, w, 10)
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(40)]
+    for st in streams:
+        with torch.cuda.stream(st):
+            t = words_to_tensor(O.BFLOAT16, w)
+            comp, sizes, _ = dg.compress_data(True, [t], False, None)
+        st.synchronize()
+        n = int(sizes[0])
+        assert n == want.size and (comp[0, :n].cpu().numpy() == want).all()
+    assert 0 < L.dgpu_debug_stream_state_count() <= 32
+    torch.cuda.synchronize()
+    assert L.dgpu_release_all_stream_state() > 0
+    assert L.dgpu_debug_stream_state_count() == 0
+    # and the library keeps working afterwards
+    t = words_to_tensor(O.BFLOAT16, w)
+    comp, sizes, _ = dg.compress_data(True, [t], False, None)
+    assert int(sizes[0]) == want.size
+
+
+def test_bench_two_ranks_on_one_device(dg):
+    # python bench.py --gpus 2 starts its own two ranks (gloo here, both on GPU 0: the box has one GPU);
+    # the line must describe a 2-rank job
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DGPU_BENCH_ONE_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
+                        "--steps", "3", "--warmup", "1", "--batch", "64", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["world_size_seen_by_backend"] == 2 and len(d["per_rank_ms_per_step"]) == 2
+    assert d["round_trip_bit_exact"] and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 2 * d["config"]["per_gpu_batch_bytes"] / (d["ms_per_step"] * 1e-3) / 1e9) < 0.05 * d["value"]
 
 
 def test_large_single_element(dg):

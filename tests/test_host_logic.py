@@ -1,0 +1,42 @@
+"""Host-side logic that needs no GPU: the build helper and bench.py's launch rules."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_needs_build_lists_existing_sources():
+    from dietgpu_amd import build as b
+
+    deps = b._deps()
+    assert all(os.path.exists(d) for d in deps), [d for d in deps if not os.path.exists(d)]
+    names = {os.path.basename(d) for d in deps}
+    assert {"capi.hip", "format.h", "kernels_encode.h", "kernels_decode.h", "kernels_stats.h", "dietgpu_amd.h"} <= names
+    assert b.needs_build() in (True, False)  # must not raise whether or not the library exists
+    if os.path.exists(b.LIB_PATH):
+        assert b.build() == b.LIB_PATH  # no force: returns without compiling when up to date
+
+
+def _bench(args, env_extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                          timeout=300, env=env)
+
+
+def test_bench_refuses_fewer_gpus_than_asked():
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        return  # a multi-GPU box would really run it
+    p = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {})
+    assert p.returncode != 0
+    assert "--gpus 2 asked for" in p.stderr and "{" not in p.stdout  # no JSON line with a smaller n_gpus
+
+
+def test_bench_checks_world_size_against_flag():
+    p = _bench(["--gpus", "1"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
+    p = _bench(["--gpus", "0"], {})
+    assert p.returncode != 0

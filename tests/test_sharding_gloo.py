@@ -40,6 +40,8 @@ def _worker(rank, world, port, num_elements, q):
     local = torch.tensor(sizes, dtype=torch.int32)
     full = D.gather_sizes(local, num_elements)
     t = D.max_over_ranks(1.0 + rank, torch.device("cpu"))
+    per_rank = D.gather_scalars(10.0 + rank, torch.device("cpu"))
+    assert per_rank == [10.0 + r for r in range(world)]
     dist.barrier()
     q.put((rank, start, end, full.tolist(), t))
     dist.destroy_process_group()

@@ -82,6 +82,7 @@ if __name__ == "__main__":
     elif sys.argv[1] == "timeline":
         timeline(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 40)
     elif sys.argv[1] == "pmcrows":
-        pmcrows(sys.argv[2:])
+        only = [a.split("=", 1)[1] for a in sys.argv[2:] if a.startswith("--only=")]
+        pmcrows([a for a in sys.argv[2:] if not a.startswith("--only=")], *(only[:1]))
     else:
         pmc(sys.argv[2:])
