@@ -762,7 +762,13 @@ int arrivalCounters(StreamLease& lease, uint32_t** out, uint32_t** acc) {
     uint32_t* p = nullptr;
     const size_t words = 65536 + (size_t)kAccElements * kNumSymbols;
     DGPU_HIP(hipMalloc((void**)&p, words * sizeof(uint32_t)));
-    DGPU_HIP(hipMemset(p, 0, words * sizeof(uint32_t)));  // once per (device, stream); synchronous
+    // once per (device, stream), ordered on the caller's stream ahead of the kernels that use the
+    // counters (a plain hipMemset runs on the null stream, which non-blocking streams do not wait for)
+    hipError_t me = hipMemsetAsync(p, 0, words * sizeof(uint32_t), lease.stream());
+    if (me != hipSuccess) {
+      (void)hipFree(p);
+      return fail(DGPU_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(me));
+    }
     s->counters = p;
   }
   *out = s->counters;
