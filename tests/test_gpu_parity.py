@@ -918,6 +918,68 @@ def test_bench_two_ranks_on_one_device(dg):
     assert abs(d["value"] - 2 * 2 * d["config"]["per_gpu_batch_bytes"] / (d["ms_per_step"] * 1e-3) / 1e9) < 0.05 * d["value"]
 
 
+# ------------------------------------------------- against the reference itself (oracle/_ref)
+def _ref():
+    from oracle import ref as R
+
+    if not R.available():
+        pytest.skip("oracle/_ref not built (needs /root/reference: make -C oracle ref)")
+    return R
+
+
+@pytest.mark.parametrize("prob_bits", [9, 10, 11])
+def test_hip_archives_equal_the_reference_and_interoperate(dg, prob_bits):
+    # The reference's own sources, executed on the CPU SIMT emulation (oracle/ref_shim/): the HIP encoder's
+    # archives equal its archives (indeterminate header bytes blanked), the REFERENCE decoder reads HIP
+    # archives and the HIP decoder reads the reference's.
+    from refmask import mask_ans, mask_float
+
+    R = _ref()
+    xs = [refgen.generate_symbols(n, lam) for n, lam in ((1, 1.0), (4096, 10.0), (4097, 100.0), (70001, 20.0), (0, 1.0),
+                                                        (3 * 8 * 4096 + 11, 1000.0))]
+    for ck in (False, True):
+        got = gpu_ans_encode(dg, xs, prob_bits, ck)
+        want = R.ans_encode_batch(xs, prob_bits, ck)
+        for x, g, w in zip(xs, got, want):
+            assert g.size == w.size and not (mask_ans(g) != mask_ans(w)).any(), (x.size, ck)
+        outs, ok, osz, rc = R.ans_decode_batch(got, [x.size for x in xs], prob_bits, ck)  # reference reads HIP archives
+        assert rc == 0 and ok.all() and all((o == x).all() for o, x in zip(outs, xs))
+        outs, status, _ = gpu_ans_decode(dg, want, [x.size for x in xs], prob_bits, ck)   # HIP reads the reference's
+        assert status.all() and all((o == x).all() for o, x in zip(outs, xs))
+    for ft in (O.FLOAT16, O.BFLOAT16, O.FLOAT32):
+        ws = [refgen.generate_floats(ft, n) for n in (1, 17, 4096, 8 * 4096 + 3, 50003)]
+        ts = [words_to_tensor(ft, w) for w in ws]
+        comp, sizes, _ = dg.compress_data(True, ts, True, prob_bits=prob_bits)
+        hs, hc = sizes.cpu().numpy(), comp.cpu().numpy()
+        got = [hc[i, : hs[i]].copy() for i in range(len(ws))]
+        want = R.float_compress_batch(ft, ws, prob_bits, True)
+        for w_, g, r in zip(ws, got, want):
+            assert g.size == r.size and not (mask_float(g) != mask_float(r)).any(), (ft, w_.size)
+        outs, ok, osz, rc = R.float_decompress_batch(ft, got, [w.size for w in ws], prob_bits, True)
+        assert rc == 0 and ok.all() and all((o == w).all() for o, w in zip(outs, ws))
+        outs = [torch.empty_like(t) for t in ts]
+        dg.decompress_data(True, [to_dev_bytes(r) for r in want], outs, True, prob_bits=prob_bits)
+        assert all((tensor_to_words(ft, o) == w).all() for o, w in zip(outs, ws))
+
+
+def test_hip_statistics_equal_the_reference(dg):
+    R = _ref()
+    rng = np.random.default_rng(77)
+    x = (rng.exponential(9.0, 100000) % 256).astype(np.uint8)
+    t = to_dev_bytes(x)
+    hist = torch.zeros((1, 256), dtype=torch.int32, device=DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert dg.lib().dgpu_ans_histogram_batch_stride(1, C.c_void_p(t.data_ptr()), x.size, x.size, C.c_void_p(hist.data_ptr()), st) == 0
+    assert (hist.cpu().numpy()[0].astype(np.uint32) == R.histogram(x)).all()
+    counts = np.stack([np.bincount(x[: 1000 * (k + 1)], minlength=256) for k in range(40)]).astype(np.uint32)
+    totals = counts.sum(axis=1).astype(np.uint32)
+    for P in (9, 10, 11):
+        got = gpu_normalize(dg, counts, totals, P).reshape(40, 256, 4)
+        want = R.normalize_batch(counts, totals, P)
+        live = want[:, :, 0] > 0
+        assert (got[:, :, :2] == want[:, :, :2]).all() and (got[live] == want[live]).all()
+
+
 def test_large_single_element(dg):
     # float_test.py:66-76 shape class: one big tensor (many tiles -> multi-window look-back)
     n = 40 * 1000 * 1000 + 7
