@@ -44,6 +44,7 @@ _SIGS = {
     "dgpu_prof_summary": (i32, [C.c_char_p, sz]),
     "dgpu_debug_set_absent_workgroups": (None, [u32]),
     "dgpu_debug_set_param_cache": (None, [i32]),
+    "dgpu_debug_set_fused": (None, [i32]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)

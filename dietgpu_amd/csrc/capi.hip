@@ -19,6 +19,7 @@
 #include "format.h"
 #include "kernels_decode.h"
 #include "kernels_encode.h"
+#include "kernels_encode_fused.h"
 #include "kernels_stats.h"
 
 using namespace dgpu;
@@ -128,8 +129,10 @@ struct StreamState {
   uint8_t* slab = nullptr;
   size_t slabCap = 0;
   std::vector<void*> retired;
-  // 65536 arrival counters + kAccElements x 256 histogram counters, zero at rest
+  // 65536 arrival counters + kAccElements x 256 histogram counters (zero at rest), then the fused
+  // encoder's 65536 ready flags (epoch-valued) and its ticket / exit counters (zero at rest)
   uint32_t* counters = nullptr;
+  uint32_t fusedEpoch = 0;  // value the ready flags of the last fused call were raised to
 
   void releaseDeviceMemory() {
     for (void* p : retired) (void)hipFree(p);
@@ -612,6 +615,21 @@ struct HostParams {
   std::vector<uint32_t> sizes;
 };
 
+// uniform size (0 if the sizes differ) and 16-byte alignment of every input pointer of a pointer batch
+void batchShape(const HostParams& hp, uint32_t* uniformSize, bool* aligned16) {
+  uint32_t u = hp.sizes.empty() ? 0u : hp.sizes[0];
+  for (uint32_t sz : hp.sizes) {
+    if (sz != u) {
+      u = 0;
+      break;
+    }
+  }
+  bool al = true;
+  for (uint64_t p : hp.inPtrs) al = al && (p % 16 == 0);
+  *uniformSize = u;
+  *aligned16 = al;
+}
+
 int uploadParams(
     ParamLease& lease, hipStream_t stream, const HostParams& hp,
     const uint64_t** inPtrs_dev, const uint64_t** outPtrs_dev, const uint32_t** sizes_dev) {
@@ -754,13 +772,17 @@ bool histAccumulates(uint32_t B, uint32_t maxBytes) {
 // (HistFuse): 65536 u32 per (device, stream), zero at rest -- the kernel that uses
 // them puts them back to zero.  Keyed by stream because calls on one stream are
 // ordered while calls on different streams may overlap.
+constexpr size_t kCounterWordsArrive = 65536;
+constexpr size_t kCounterWordsAcc = (size_t)kAccElements * kNumSymbols;
+constexpr size_t kCounterWordsReady = 65536;
+constexpr size_t kCounterWordsTickets = (kFusedMaxClasses + 1) * kFusedTicketStride;
 int arrivalCounters(StreamLease& lease, uint32_t** out, uint32_t** acc) {
   hipError_t e = hipSuccess;
   StreamState* s = lease.state(&e);
   if (!s) return fail(DGPU_ERR_HIP, std::string("stream state: ") + hipGetErrorString(e));
   if (!s->counters) {
     uint32_t* p = nullptr;
-    const size_t words = 65536 + (size_t)kAccElements * kNumSymbols;
+    const size_t words = kCounterWordsArrive + kCounterWordsAcc + kCounterWordsReady + kCounterWordsTickets;
     DGPU_HIP(hipMalloc((void**)&p, words * sizeof(uint32_t)));
     // once per (device, stream), ordered on the caller's stream ahead of the kernels that use the
     // counters (a plain hipMemset runs on the null stream, which non-blocking streams do not wait for)
@@ -772,8 +794,120 @@ int arrivalCounters(StreamLease& lease, uint32_t** out, uint32_t** acc) {
     s->counters = p;
   }
   *out = s->counters;
-  *acc = s->counters + 65536;
+  *acc = s->counters + kCounterWordsArrive;
   return DGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Fused histogram + encode (kernels_encode_fused.h): taken for uniform batches.
+std::atomic<int> g_fusedMode{-1};  // -1: environment DGPU_FUSED (default on), 0 / 1: forced (dgpu_debug_set_fused)
+bool fusedEnabled() {
+  const int m = g_fusedMode.load();
+  if (m >= 0) return m != 0;
+  static const bool env = [] {
+    const char* e = getenv("DGPU_FUSED");
+    return !(e && e[0] == '0');
+  }();
+  return env;
+}
+
+template <int P, uint32_t FT>
+uint32_t fusedGridPF(uint32_t tickets) {
+  static const uint32_t perCu = [] {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (k_ans_encode_fused<P, FT>), 256, fusedLdsBytes(P, FT)) != hipSuccess || n < 1) n = 1;
+    return (uint32_t)n;
+  }();
+  static const uint32_t knob = [] {
+    const char* e = getenv("DGPU_FUSED_WG_PER_CU");  // experiment knob
+    return e ? (uint32_t)atoi(e) : 0u;
+  }();
+  const uint32_t use = knob ? std::min(knob, perCu) : perCu;
+  return std::max(1u, std::min(tickets, use * numComputeUnits()));
+}
+template <int P, uint32_t FT>
+int launchFusedPF(const FusedArgs& a, uint32_t grid, hipStream_t stream) {
+  DGPU_LAUNCH("k_ans_encode_fused", stream, (k_ans_encode_fused<P, FT>), dim3(grid), dim3(256), fusedLdsBytes(P, FT), stream, a);
+  DGPU_HIP(hipGetLastError());
+  return DGPU_OK;
+}
+
+// Is the batch one the fused kernel takes?  (uniformSize: every element has that many symbols, 0 = ragged)
+bool fusedEligible(uint32_t B, uint32_t uniformSize, bool inputsAligned16, const uint32_t* hist_dev) {
+  if (!fusedEnabled() || hist_dev || !inputsAligned16 || B == 0 || B > kCounterWordsReady) return false;
+  constexpr uint32_t kTileSymbols = kBlocksPerTile * kBlockSize;
+  if (uniformSize == 0 || uniformSize % kTileSymbols) return false;
+  return uniformSize / kTileSymbols <= kFusedMaxTiles;
+}
+
+int encodeFused(
+    TempArena& arena, StreamLease& lease, hipStream_t stream, int P, bool useChecksum, uint32_t B,
+    const BatchView& in, const BatchView& archives, uint32_t floatType, uint32_t size,
+    const uint32_t* checksumTemp, uint32_t* outSize_dev) {
+  const uint32_t T = size / (kBlocksPerTile * kBlockSize);
+  uint32_t *arrive = nullptr, *acc = nullptr;
+  int rc = arrivalCounters(lease, &arrive, &acc);
+  if (rc) return rc;
+  hipError_t e = hipSuccess;
+  StreamState* st = lease.state(&e);
+  if (!st) return fail(DGPU_ERR_HIP, std::string("stream state: ") + hipGetErrorString(e));
+  uint32_t* ready = st->counters + kCounterWordsArrive + kCounterWordsAcc;
+  uint32_t* tickets = ready + kCounterWordsReady;
+  if (++st->fusedEpoch == 0) {  // wrapped: flags of 2^32 calls ago would read as raised
+    DGPU_HIP(hipMemsetAsync(ready, 0, kCounterWordsReady * 4, stream));
+    st->fusedEpoch = 1;
+  }
+
+  DGPU_ALLOC(table, uint4, arena, (size_t)B * kNumSymbols);
+  DGPU_ALLOC(histParts, uint32_t, arena, (size_t)B * T * kNumSymbols);
+  DGPU_ALLOC(tileDesc, uint64_t, arena, (size_t)B * T);
+
+  uint32_t grid = 1;
+  DGPU_ENCODE_DISPATCH(P, floatType, grid = (fusedGridPF<kP, kFT>(B * T)));
+  DGPU_ALLOC(spill, uint16_t, arena, (size_t)grid * kBlocksPerTile * encSpillSlotWords(P));
+
+  FusedArgs f;
+  f.in = in;
+  f.out = archives;
+  f.numInBatch = B;
+  f.tiles = T;
+  f.size = size;
+  f.numClasses = std::min(B, kFusedMaxClasses);
+  f.encTable = table;
+  f.histParts = histParts;
+  f.tileDesc = tileDesc;
+  f.arrive = arrive;
+  f.ready = ready;
+  f.epoch = st->fusedEpoch;
+  f.tickets = tickets;
+  f.spill = spill;
+  f.outSize = outSize_dev;
+  f.useChecksum = (useChecksum && floatType) ? 1 : 0;
+  f.checksum = (useChecksum && floatType) ? checksumTemp : nullptr;
+  f.absentModulo = absentWorkgroupModulo();
+  NormalizeArgs& n = f.norm;
+  n.sizes = in;
+  n.hist = histParts;
+  n.histAcc = nullptr;
+  n.histParts = T;
+  n.probBits = P;
+  n.encTable = table;
+  n.refTable = nullptr;
+  n.out = archives;
+  n.writeHeader = 1;
+  n.floatType = floatType;
+  n.useChecksum = (useChecksum && !floatType) ? 1 : 0;
+  n.checksum = (useChecksum && !floatType) ? checksumTemp : nullptr;
+  n.outSize = outSize_dev;
+  n.floatUseChecksum = (useChecksum && floatType) ? 1 : 0;
+  n.tileDesc = nullptr;
+  n.maxTiles = T;
+  n.ticket = nullptr;
+  n.claims = nullptr;
+  n.numInBatch = B;
+  n.inKernelConsumer = 1;
+  DGPU_ENCODE_DISPATCH(P, floatType, rc = (launchFusedPF<kP, kFT>(f, grid, stream)));
+  return rc;
 }
 
 // Shared tail of every encode entry point: [checksum] -> histogram (+ fused
@@ -786,6 +920,7 @@ int arrivalCounters(StreamLease& lease, uint32_t** out, uint32_t** acc) {
 int encodeCommon(
     TempArena& arena, StreamLease& lease, hipStream_t stream, int P, bool useChecksum, uint32_t B,
     const BatchView& in, const BatchView& archives, uint32_t floatType, uint32_t maxSize,
+    uint32_t uniformSize /* != 0: every element has this many symbols */, bool inputsAligned16,
     const uint32_t* hist_dev /*may be null*/, uint32_t* outSize_dev) {
   const uint32_t wordBytes = floatType ? floatWordBytes(floatType) : 1u;
   const uint32_t maxTiles = tilesFor(maxSize);
@@ -800,6 +935,11 @@ int encodeCommon(
     dim3 grid(gridX(maxSize, 64 * 1024, 64), B);
     DGPU_LAUNCH("k_checksum", stream, k_checksum, grid, dim3(256), 0, stream, in, (const uint32_t*)nullptr, (const uint8_t*)nullptr, checksumTemp);
     DGPU_HIP(hipGetLastError());
+  }
+
+  if (fusedEligible(B, uniformSize, inputsAligned16, hist_dev)) {
+    return encodeFused(arena, lease, stream, P, useChecksum, B, in, archives, floatType, uniformSize, checksumTemp,
+                       outSize_dev);
   }
 
   DGPU_ALLOC(table, uint4, arena, (size_t)B * kNumSymbols);
@@ -828,6 +968,7 @@ int encodeCommon(
   n.ticket = ticket;
   n.claims = claims;
   n.numInBatch = B;
+  n.inKernelConsumer = 0;
 
   if (!hist_dev) {
     const bool accumulate = histAccumulates(B, maxSize * wordBytes);
@@ -929,7 +1070,16 @@ int ansEncodeImpl(
     in = *strideIn;
     out = *strideOut;
   }
-  int rc = encodeCommon(arena, streamLease, stream, P, useChecksum != 0, B, in, out, 0, maxSize, histogram_dev, outSize_dev);
+  uint32_t uniformSize = 0;
+  bool aligned16 = false;
+  if (hp) {
+    batchShape(*hp, &uniformSize, &aligned16);
+  } else {
+    uniformSize = strideIn->uniformSize;
+    aligned16 = strideIn->base % 16 == 0 && (B <= 1 || strideIn->stride % 16 == 0);
+  }
+  int rc = encodeCommon(arena, streamLease, stream, P, useChecksum != 0, B, in, out, 0, maxSize, uniformSize, aligned16,
+                        histogram_dev, outSize_dev);
   if (tempUsed) *tempUsed = arena.requested();
   return rc;
 }
@@ -955,7 +1105,11 @@ int floatCompressImpl(
   BatchView out = viewPointers(outP, nullptr, 0);
 
   // No exponent plane in temp memory: the encoder splits the float words itself.
-  rc = encodeCommon(arena, streamLease, stream, P, useChecksum != 0, B, in, out, ft, maxSize, nullptr, outSize_dev);
+  uint32_t uniformSize = 0;
+  bool aligned16 = false;
+  batchShape(hp, &uniformSize, &aligned16);
+  rc = encodeCommon(arena, streamLease, stream, P, useChecksum != 0, B, in, out, ft, maxSize, uniformSize, aligned16, nullptr,
+                    outSize_dev);
   if (tempUsed) *tempUsed = arena.requested();
   return rc;
 }
@@ -1128,6 +1282,7 @@ uint32_t absentWorkgroupModulo() { return g_absentModulo.load(); }
 extern "C" {
 void dgpu_debug_set_absent_workgroups(uint32_t modulo) { g_absentModulo.store(modulo); }
 void dgpu_debug_set_param_cache(int on) { g_paramCacheEnabled.store(on != 0); }
+void dgpu_debug_set_fused(int mode) { g_fusedMode.store(mode < 0 ? -1 : (mode != 0)); }
 
 int dgpu_release_stream_state(void* stream) { return streamRegistry().release((hipStream_t)stream, false); }
 int dgpu_release_all_stream_state(void) { return streamRegistry().release(nullptr, true); }
@@ -1187,7 +1342,7 @@ uint32_t dgpu_float_max_compressed_size(uint32_t ft, uint32_t n) {
 
 static size_t encodeTempBytes(uint32_t B, uint32_t maxBytes, uint32_t wordBytes, bool spills) {
   size_t tiles = std::max(tilesFor(maxBytes), 1u);
-  size_t parts = histPartsFor(B, maxBytes * wordBytes);
+  size_t parts = std::max<size_t>(histPartsFor(B, maxBytes * wordBytes), std::min<size_t>(tiles, kFusedMaxTiles));
   size_t t = 0;
   t += alignUp((size_t)B * 4, kTempAlign);                                        // checksums
   t += alignUp((size_t)B * parts * kNumSymbols * 4, kTempAlign);                  // partial histograms
@@ -1532,6 +1687,7 @@ int dgpu_ans_calc_weights(
   n.ticket = nullptr;
   n.claims = nullptr;
   n.numInBatch = numInBatch;
+  n.inKernelConsumer = 0;
   hipLaunchKernelGGL(k_normalize, dim3(numInBatch), dim3(256), 0, (hipStream_t)stream, n);
   DGPU_HIP(hipGetLastError());
   return DGPU_OK;

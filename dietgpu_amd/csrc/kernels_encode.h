@@ -190,6 +190,11 @@ struct ChunkSource<0> {  // raw bytes: the symbols are the input
     return r;
   }
   __device__ __forceinline__ void consume(const Raw& r, uint32_t, uint32_t hl, uint8_t* ring) const { *(uint4*)(ring + hl * 16u) = r.v; }
+  // split without the ring write (fused kernel: the symbol bytes stay in registers for a while)
+  static constexpr uint32_t kCompRegs = 4;
+  __device__ __forceinline__ void splitStore(const Raw& r, uint32_t, uint32_t, uint32_t (&comp)[kCompRegs]) const {
+    comp[0] = r.v.x; comp[1] = r.v.y; comp[2] = r.v.z; comp[3] = r.v.w;
+  }
   __device__ __forceinline__ uint32_t wordAt(uint32_t i) const { return in[i]; }
   __device__ __forceinline__ uint32_t splitAt(uint32_t, uint32_t w, bool) const { return w; }
 };
@@ -217,10 +222,17 @@ struct ChunkSource16 {
     r.b = streamLoad<DGPU_NT_ENC_LOADS != 0>(&p[1]);
     return r;
   }
-  // FloatTypeInfo<FT>::split (GpuFloatUtils.cuh:111-115, 141-147) on packed pairs
+  static constexpr uint32_t kCompRegs = 4;
   __device__ __forceinline__ void consume(const Raw& r, uint32_t c, uint32_t hl, uint8_t* ring) const {
+    uint32_t comp[4];
+    splitStore(r, c, hl, comp);
+    *(uint4*)(ring + hl * 16u) = make_uint4(comp[0], comp[1], comp[2], comp[3]);
+  }
+  // FloatTypeInfo<FT>::split (GpuFloatUtils.cuh:111-115, 141-147) on packed pairs: the non-compressed
+  // bytes go to the archive, the compressed (exponent) bytes of the lane's 16 words are returned
+  __device__ __forceinline__ void splitStore(const Raw& r, uint32_t c, uint32_t hl, uint32_t (&comp)[kCompRegs]) const {
     const uint32_t x[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w};
-    uint32_t comp[4], rest[4];
+    uint32_t rest[4];
     if (FT == kFloat16) {
       // comp = w >> 8 (bytes 1, 3 of each dword), nonComp = w & 0xff (bytes 0, 2)
 #pragma unroll
@@ -248,7 +260,6 @@ struct ChunkSource16 {
       }
     }
     streamStore<DGPU_NT_ENC_STORES != 0>(&((uint4*)(nc + c * 512u))[hl], make_uint4(rest[0], rest[1], rest[2], rest[3]));
-    *(uint4*)(ring + hl * 16u) = make_uint4(comp[0], comp[1], comp[2], comp[3]);
   }
   __device__ __forceinline__ uint32_t wordAt(uint32_t i) const { return in[i]; }
   __device__ __forceinline__ uint32_t splitAt(uint32_t i, uint32_t w, bool valid) const {
@@ -290,8 +301,14 @@ struct ChunkSource<kFloat32> {  // 4-byte words: comp byte + 24 non-comp bits (u
     r.v[1] = streamLoad<DGPU_NT_ENC_LOADS != 0>(&p[1]);
     return r;
   }
-  // FloatTypeInfo<kFloat32>::split (GpuFloatUtils.cuh:181-185): v = rotl(w, 1)
+  static constexpr uint32_t kCompRegs = 2;
   __device__ __forceinline__ void consume(const Raw& r, uint32_t c, uint32_t hl, uint8_t* ring) const {
+    uint32_t comp[2];
+    splitStore(r, c, hl, comp);
+    *(uint2*)(ring + hl * 8u) = make_uint2(comp[0], comp[1]);
+  }
+  // FloatTypeInfo<kFloat32>::split (GpuFloatUtils.cuh:181-185): v = rotl(w, 1)
+  __device__ __forceinline__ void splitStore(const Raw& r, uint32_t c, uint32_t hl, uint32_t (&comp)[kCompRegs]) const {
     uint32_t v[8];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -300,7 +317,7 @@ struct ChunkSource<kFloat32> {  // 4-byte words: comp byte + 24 non-comp bits (u
       v[4 * j + 2] = __builtin_amdgcn_alignbit(r.v[j].z, r.v[j].z, 31);
       v[4 * j + 3] = __builtin_amdgcn_alignbit(r.v[j].w, r.v[j].w, 31);
     }
-    uint32_t comp[2], hi[2], lo[4];
+    uint32_t hi[2], lo[4];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       // bytes 2 (high non-comp byte) and 3 (comp) of four words -> one dword each
@@ -313,7 +330,6 @@ struct ChunkSource<kFloat32> {  // 4-byte words: comp byte + 24 non-comp bits (u
     }
     streamStore<DGPU_NT_ENC_STORES != 0>((uint4*)(nc2 + c * 256u + hl * 8u), make_uint4(lo[0], lo[1], lo[2], lo[3]));
     *(uint2*)(nc1 + c * 256u + hl * 8u) = make_uint2(hi[0], hi[1]);
-    *(uint2*)(ring + hl * 8u) = make_uint2(comp[0], comp[1]);
   }
   __device__ __forceinline__ uint32_t wordAt(uint32_t i) const { return in[i]; }
   __device__ __forceinline__ uint32_t splitAt(uint32_t i, uint32_t w, bool valid) const {

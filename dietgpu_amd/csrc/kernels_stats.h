@@ -69,17 +69,23 @@ struct NormalizeArgs {
   uint32_t* ticket;          // nullable
   uint32_t* claims;          // [maxTiles][numInBatch] nullable (encoder's tile claim words)
   uint32_t numInBatch;
+  // != 0: called from inside the fused encode kernel (k_ans_encode_fused).  The table is read by other
+  // workgroups of the SAME kernel, possibly on other XCDs: it is stored write-through; and the header word
+  // `totalCompressedWords` is left to the element's last tile (two XCDs must not hold the same bytes dirty).
+  uint32_t inKernelConsumer;
 };
 
 // One 256-thread workgroup normalises batch element b.  kCoherent: the partial
 // histograms were written by other workgroups of the SAME kernel (write-through
 // agent-scope stores) and are read with agent-scope loads.
+// `scratch`: kNormScratchWords u32 of LDS, 16-byte aligned, free for the duration of the call.
+constexpr uint32_t kNormScratchWords = 3u * kNumSymbols + 4u;
 template <bool kCoherent>
-__device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const uint32_t b) {
-  __shared__ uint32_t sKeys[kNumSymbols];
-  __shared__ uint32_t sSorted[kNumSymbols];
-  __shared__ uint32_t sPdf[kNumSymbols];
-  __shared__ uint32_t sWave[4];
+__device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const uint32_t b, uint32_t* scratch) {
+  uint32_t* sKeys = scratch;
+  uint32_t* sSorted = scratch + kNumSymbols;
+  uint32_t* sPdf = scratch + 2u * kNumSymbols;
+  uint32_t* sWave = scratch + 3u * kNumSymbols;
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
@@ -226,7 +232,13 @@ __device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const u
     e.y = m;
     e.z = cdfTerm;
     e.w = ((W - pdf) & 0xffffffu) | (sh << 24);
-    a.encTable[b * kNumSymbols + tid] = e;
+    if (a.inKernelConsumer) {
+      uint64_t* dst = (uint64_t*)&a.encTable[b * kNumSymbols + tid];
+      __hip_atomic_store(dst, (uint64_t)e.x | ((uint64_t)e.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(dst + 1, (uint64_t)e.z | ((uint64_t)e.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      a.encTable[b * kNumSymbols + tid] = e;
+    }
   }
   if (a.refTable) {
     // the reference's table (pdf, cdf, 33-bit magic, shift), :349-358
@@ -253,7 +265,16 @@ __device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const u
       h.checksum = (a.useChecksum && a.checksum) ? a.checksum[b] : 0u;
       h.unused0 = 0;
       h.unused1 = 0;
-      *(AnsHeader*)ans = h;
+      if (a.inKernelConsumer && nb != 0) {
+        // every word but totalCompressedWords (written by the last tile, maybe from another XCD)
+        uint32_t* hw = (uint32_t*)ans;
+        hw[0] = h.magicAndVersion;
+        hw[1] = h.numBlocks;
+        hw[2] = h.totalUncompressedWords;
+        *(uint4*)(hw + 4) = make_uint4(h.options, h.checksum, 0u, 0u);
+      } else {
+        *(AnsHeader*)ans = h;
+      }
       if (nb == 0) {
         // empty element: no encode tile will run for it
         if (a.outSize) a.outSize[b] = ansOffsetInArchive(a.floatType, total) + ansOverhead(0);
@@ -271,7 +292,10 @@ __device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const u
 }
 
 // Stand-alone normalisation (caller-supplied histograms, dgpu_ans_calc_weights).  grid = B.
-__global__ __launch_bounds__(256) void k_normalize(NormalizeArgs a) { normalizeElement<false>(a, blockIdx.x); }
+__global__ __launch_bounds__(256) void k_normalize(NormalizeArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t sScratch[kNormScratchWords];
+  normalizeElement<false>(a, blockIdx.x, sScratch);
+}
 
 // ---------------------------------------------------------------------------
 // Histogram -> normalisation hand-off inside one kernel.  Every histogram
@@ -355,6 +379,7 @@ __device__ __forceinline__ void histStore(uint32_t* __restrict__ hist, uint32_t 
     return;
   }
   __shared__ uint32_t sLast;
+  __shared__ __attribute__((aligned(16))) uint32_t sScratch[kNormScratchWords];
   if (f.acc) {
     // few large elements: thousands of workgroups per element; their counts meet in
     // 256 atomic counters instead of thousands of partial histograms
@@ -371,7 +396,7 @@ __device__ __forceinline__ void histStore(uint32_t* __restrict__ hist, uint32_t 
   __syncthreads();
   if (sLast) {  // uniform
     if (tid == 0) __hip_atomic_store(&f.arrive[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    normalizeElement<true>(f.norm, b);
+    normalizeElement<true>(f.norm, b, sScratch);
   }
 }
 

@@ -257,6 +257,14 @@ void dgpu_debug_set_absent_workgroups(uint32_t modulo);
  * steady-state one. */
 void dgpu_debug_set_param_cache(int on);
 
+/* Measurement / test hook: uniform batches (every element the same whole number of 32 Ki-symbol
+ * tiles, <= 32 of them, 16-byte aligned inputs, no caller histogram) are encoded by ONE kernel that
+ * reads the input once (histogram + normalisation + encode fused).
+ * 0 forces the two-kernel path (histogram kernel, then encode kernel), 1 forces the fused one where
+ * eligible, -1 restores the default (environment DGPU_FUSED, on unless "0").  Archives are
+ * byte-identical either way. */
+void dgpu_debug_set_fused(int mode);
+
 #ifdef __cplusplus
 }
 #endif
