@@ -800,13 +800,13 @@ int arrivalCounters(StreamLease& lease, uint32_t** out, uint32_t** acc) {
 
 // ---------------------------------------------------------------------------
 // Fused histogram + encode (kernels_encode_fused.h): taken for uniform batches.
-std::atomic<int> g_fusedMode{-1};  // -1: environment DGPU_FUSED (default on), 0 / 1: forced (dgpu_debug_set_fused)
+std::atomic<int> g_fusedMode{-1};  // -1: environment DGPU_FUSED (default off), 0 / 1: forced (dgpu_debug_set_fused)
 bool fusedEnabled() {
   const int m = g_fusedMode.load();
   if (m >= 0) return m != 0;
   static const bool env = [] {
     const char* e = getenv("DGPU_FUSED");
-    return !(e && e[0] == '0');
+    return e && e[0] == '1';  // opt-in: measured slower than the two-kernel path
   }();
   return env;
 }
@@ -885,6 +885,11 @@ int encodeFused(
   f.useChecksum = (useChecksum && floatType) ? 1 : 0;
   f.checksum = (useChecksum && floatType) ? checksumTemp : nullptr;
   f.absentModulo = absentWorkgroupModulo();
+  static const uint32_t stagger = [] {
+    const char* e = getenv("DGPU_FUSED_STAGGER");  // experiment knob
+    return e ? (uint32_t)strtoul(e, nullptr, 0) : 0u;
+  }();
+  f.staggerSleeps = stagger;
   NormalizeArgs& n = f.norm;
   n.sizes = in;
   n.hist = histParts;

@@ -84,8 +84,13 @@ constexpr uint32_t kFlushRows = 8;
 // words of spill slot per block: the worst case of a block (whole vectors)
 __host__ __device__ constexpr uint32_t encSpillSlotWords(int P) { return roundUp(encStageWords(P), 8u) + 8u; }
 
+// raw bytes (spilling variant, DGPU_RAW_SPILLS): byte streams carry more bits per symbol than exponents
+#ifndef DGPU_RAW_STAGE_WORDS
+#define DGPU_RAW_STAGE_WORDS 1664
+#endif
+constexpr uint32_t kSpillStageWordsRaw = DGPU_RAW_STAGE_WORDS;
 __host__ __device__ constexpr uint32_t encStageCap(int P, bool spill, uint32_t ft) {
-  return spill ? (ft == kFloat16 ? kSpillStageWordsFp16 : kSpillStageWords) : encStageWords(P);
+  return spill ? (ft == kFloat16 ? kSpillStageWordsFp16 : ft == 0 ? kSpillStageWordsRaw : kSpillStageWords) : encStageWords(P);
 }
 // Blocks per tile = per workgroup: 8 (256 threads), or 4 (128 threads) for batches whose elements have
 // at most 4 blocks -- an 8-block tile would leave half of its waves without a block there.

@@ -76,6 +76,7 @@ struct FusedArgs {
   uint32_t useChecksum;    // float header only
   const uint32_t* checksum;  // [B] nullable (float header only)
   uint32_t absentModulo;   // test hook (see EncodeArgs)
+  uint32_t staggerSleeps;  // start delay, in s_sleep(127) units, per dispatch round of the grid (blockIdx / 256)
   NormalizeArgs norm;      // for normalizeElement: hist = histParts, histParts = T, inKernelConsumer = 1
 };
 
@@ -129,6 +130,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
   if (a.absentModulo && blockIdx.x % a.absentModulo == 1u) {
     for (int i = 0; i < 150; ++i) __builtin_amdgcn_s_sleep(127);  // test hook: becomes resident ~0.5 ms late
+  }
+
+  // Stagger: the workgroups that share a CU (blockIdx i, i + 256, i + 512, ...) start a fraction of a
+  // tile time apart, so that they sit in different phases: while one waits for a table or a look-back
+  // the others keep the SIMDs busy.
+  {
+    // bit 31 of the knob: phase class from a hash of the workgroup index instead of blockIdx / 256
+    const uint32_t q = (a.staggerSleeps >> 31) ? ((blockIdx.x * 2654435761u) >> 30) : (blockIdx.x >> 8);
+    for (uint32_t i = 0, n = q * (a.staggerSleeps & 0xffffu); i < n; ++i) __builtin_amdgcn_s_sleep(127);
   }
 
   histZero<S>(sBins, tid);
@@ -236,7 +246,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // ================= steady state ================================================================
   while (nxt != kFusedNone) {
     const uint32_t b = nxt / T, tile = nxt - b * T;
+#ifdef DGPU_PHASE_TIMING
+    const uint32_t phaseSlot = nxt;
+    if (threadIdx.x == 0 && g_phaseBuf) g_phaseBuf[(size_t)phaseSlot * 8 + 7] = blockIdx.x;
+#endif
+    DGPU_PHASE(0);
     fetchTable(b);
+    DGPU_PHASE(1);
     nxt = drawBroadcast();
     const bool haveNext = nxt != kFusedNone;
     const uint32_t bn = haveNext ? nxt / T : 0u, tn = haveNext ? nxt - bn * T : 0u;
@@ -333,10 +349,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       }
     }
     uint32_t words = outOff;
+    DGPU_PHASE(2);
 
-    if (haveNext) publishHistogram(bn, tn);
-
-    // ---- finish tile (b, tile): states, ordered compaction (look-back), copy-out: as in k_ans_encode ----
+    // ---- finish tile (b, tile), part 1: states, block sizes, and the tile's AGGREGATE descriptor --
+    // published before anything that can take long (the histogram hand-off below may include the
+    // normalisation of a whole element): the tiles behind this one only need the aggregate
     {
       ((uint32_t*)(ans + ansStatesOffset()))[block * 32u + hl] = state;
       const uint32_t padded = roundUp(words, kBlockAlignWords);
@@ -344,17 +361,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     if (hl == 0) sh->words[hw] = spilled + words;
     ldsBarrier();
-
+    uint32_t myPadded = 0, incl = 0, aggregate = 0;  // wave 0
+    uint64_t* desc = a.tileDesc + (size_t)b * T;
     if (wave == 0) {
-      uint32_t myPadded = (lane < kTB) ? roundUp(sh->words[lane], kBlockAlignWords) : 0u;
-      uint32_t incl = waveInclusiveScan(myPadded, lane);
-      const uint32_t aggregate = __shfl(incl, kTB - 1, 64);
+      myPadded = (lane < kTB) ? roundUp(sh->words[lane], kBlockAlignWords) : 0u;
+      incl = waveInclusiveScan(myPadded, lane);
+      aggregate = __shfl(incl, kTB - 1, 64);
       if (lane < kTB) sh->localOff[lane] = incl - myPadded;
-
-      uint64_t* desc = a.tileDesc + (size_t)b * T;
       if (lane == 0) {
         __hip_atomic_store(&desc[tile], kDescAggregate | (uint64_t)aggregate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+    }
+
+    if (haveNext) publishHistogram(bn, tn);
+    DGPU_PHASE(3);
+
+    // ---- part 2: ordered compaction (look-back over the preceding tiles) and copy-out, as in k_ans_encode ----
+    if (wave == 0) {
       uint32_t exclusive = 0;
       int base = (int)tile - 1;
       while (base >= 0) {
@@ -392,6 +415,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       // nb is a multiple of 8: no odd blockWords pad entry
     }
     ldsBarrier();
+    DGPU_PHASE(4);
     {
       uint4* dst = (uint4*)(ans + ansOverhead(nb) + 2u * (size_t)(sh->tileBase + sh->localOff[hw]));
       if (spilled) {
@@ -405,6 +429,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const uint4* s4 = (const uint4*)stage;
       for (uint32_t i = hl; i < vecs; i += 32u) streamStore<DGPU_NT_ENC_STORES != 0>(&dst[i], s4[i]);
     }
+    DGPU_PHASE(5);
     ldsBarrier();  // sh->words / stage are written again by the next tile
   }
 
