@@ -1123,10 +1123,10 @@ template <int P, uint32_t FT>
 int launchDecodePF(const DecodeArgs& a, uint32_t tileBlocks, dim3 grid, hipStream_t stream) {
   if (tileBlocks == kDecBlocksPerSmallTile) {
     DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode<P, FT, kDecBlocksPerSmallTile>), grid, dim3(kDecBlocksPerSmallTile * 32u),
-                decLdsBytes(P, kDecBlocksPerSmallTile), stream, a);
+                decLdsBytes(P, FT, kDecBlocksPerSmallTile), stream, a);
   } else {
     DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode<P, FT, kDecBlocksPerTile>), grid, dim3(kDecBlocksPerTile * 32u),
-                decLdsBytes(P, kDecBlocksPerTile), stream, a);
+                decLdsBytes(P, FT, kDecBlocksPerTile), stream, a);
   }
   DGPU_HIP(hipGetLastError());
   return DGPU_OK;

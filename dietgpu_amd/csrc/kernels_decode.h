@@ -52,6 +52,20 @@ struct DecodeArgs {
 // (GpuFloatUtils.cuh:117-119,149-159,187-190) arranged so that the result sits
 // in the TOP half of a register and is stored with a d16_hi short store; the
 // pdf bits that ride along in the low 12 bits never reach the stored half.
+// Wide-store variant of the write-out (DGPU_DEC_WIDE_STORES): the row loop keeps one 2-byte (1-byte) store
+// per lane per row otherwise -- 64-byte (32-byte) pieces per half-wave, which the memory system turns into
+// 1.3x the bytes (WRITE_SIZE, profiles/).  With it, the 8 rows of a group are transposed through a 512-byte
+// (256-byte) LDS buffer per block and leave as ONE 16-byte (8-byte) store per lane: 512 (256) contiguous bytes.
+// Measured (profiles/r02_*): bf16 P=10 decode 100 -> 86 us on its own, step 243 -> 236 us, WRITE_SIZE back to
+// the algorithmic bytes.  At P = 11 the 16 KiB LUT + rings + buffers would leave 2 workgroups per CU
+// (fp16 P=11: +5 us), so the narrow stores stay there; fp32 rows are 128-byte pieces already.
+#ifndef DGPU_DEC_WIDE_STORES
+#define DGPU_DEC_WIDE_STORES 1
+#endif
+typedef __attribute__((address_space(3))) uint16_t LdsU16w;
+typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4w LdsU4w;
+
 template <uint32_t FT>
 struct RowSink;
 
@@ -64,6 +78,17 @@ struct RowSink<0> {  // raw bytes (BatchWriter, BatchProvider.cuh:16-37)
   __device__ __forceinline__ uint32_t prefetch(uint32_t) const { return 0; }
   __device__ __forceinline__ void store(uint32_t row, uint32_t e0, uint32_t) const {
     out[row * 32u] = (uint8_t)(e0 >> 24);  // 32-byte row pieces: left to the L2 to merge
+  }
+  // wide-store variant: the 8 rows of a group meet in a 256-byte LDS buffer, every lane stores 8 bytes
+  static constexpr uint32_t kXposeBytes = 256;
+  __device__ __forceinline__ uint2 prefetchGroup(uint32_t, uint32_t) const { return make_uint2(0, 0); }
+  __device__ __forceinline__ void stageRow(uint32_t xpose, uint32_t j, uint32_t hl, uint32_t e0, uint32_t) const {
+    *(__attribute__((address_space(3))) uint8_t*)(uintptr_t)(xpose + j * 32u + hl) = (uint8_t)(e0 >> 24);
+  }
+  __device__ __forceinline__ void flushGroup(uint32_t xpose, uint32_t g, uint32_t hl) const {
+    typedef uint32_t u32x2l __attribute__((ext_vector_type(2)));
+    const u32x2l v = *(const __attribute__((address_space(3))) u32x2l*)(uintptr_t)(xpose + hl * 8u);
+    *(u32x2l*)(out - hl + g * 256u + hl * 8u) = v;
   }
 };
 
@@ -80,6 +105,18 @@ struct RowSink<kFloat16> {  // word = comp << 8 | nonComp
     const uint32_t v = (r << 16) | e0;  // [sym][nc][0000 pdf]
     streamStore<DGPU_NT_DEC_STORES != 0>(&out[row * 32u], (uint16_t)(v >> 16));
   }
+  static constexpr uint32_t kXposeBytes = 512;
+  __device__ __forceinline__ uint2 prefetchGroup(uint32_t g, uint32_t hl) const { return *(const uint2*)(nc - hl + g * 256u + hl * 8u); }
+  __device__ __forceinline__ void stageRow(uint32_t xpose, uint32_t j, uint32_t hl, uint32_t e0, uint32_t r) const {
+    const uint32_t v = (r << 16) | e0;
+    *(LdsU16w*)(uintptr_t)(xpose + (j * 32u + hl) * 2u) = (uint16_t)(v >> 16);
+  }
+  __device__ __forceinline__ void flushGroup(uint32_t xpose, uint32_t g, uint32_t hl) const {
+    const u32x4w v = *(const LdsU4w*)(uintptr_t)(xpose + hl * 16u);
+    u32x4w* dst = (u32x4w*)(out - hl + g * 256u + hl * 8u);
+    if (DGPU_NT_DEC_STORES) __builtin_nontemporal_store(v, dst);
+    else *dst = v;
+  }
 };
 
 template <>
@@ -95,6 +132,19 @@ struct RowSink<kBFloat16> {  // word = (comp << 8 | nonComp) >> 1 | (nonComp & 1
     const uint32_t lo = (r << 16) | e0;                                   // [sym][nc][0000 pdf]
     const uint32_t v = __builtin_amdgcn_alignbit(r, lo, 1);               // (lo >> 1) | (r << 31)
     streamStore<DGPU_NT_DEC_STORES != 0>(&out[row * 32u], (uint16_t)(v >> 16));                    // [sign][exp][mant7]
+  }
+  static constexpr uint32_t kXposeBytes = 512;
+  __device__ __forceinline__ uint2 prefetchGroup(uint32_t g, uint32_t hl) const { return *(const uint2*)(nc - hl + g * 256u + hl * 8u); }
+  __device__ __forceinline__ void stageRow(uint32_t xpose, uint32_t j, uint32_t hl, uint32_t e0, uint32_t r) const {
+    const uint32_t lo = (r << 16) | e0;
+    const uint32_t v = __builtin_amdgcn_alignbit(r, lo, 1);
+    *(LdsU16w*)(uintptr_t)(xpose + (j * 32u + hl) * 2u) = (uint16_t)(v >> 16);
+  }
+  __device__ __forceinline__ void flushGroup(uint32_t xpose, uint32_t g, uint32_t hl) const {
+    const u32x4w v = *(const LdsU4w*)(uintptr_t)(xpose + hl * 16u);
+    u32x4w* dst = (u32x4w*)(out - hl + g * 256u + hl * 8u);
+    if (DGPU_NT_DEC_STORES) __builtin_nontemporal_store(v, dst);
+    else *dst = v;
   }
 };
 
@@ -115,6 +165,10 @@ struct RowSink<kFloat32> {  // rotr32(comp << 24 | nonComp24, 1)
     const uint32_t v = (e0 & 0xff000000u) | r;
     streamStore<DGPU_NT_DEC_STORES != 0>(&out[row * 32u], (uint32_t)__builtin_amdgcn_alignbit(v, v, 1));
   }
+  static constexpr uint32_t kXposeBytes = 0;  // 128-byte row pieces already: no transposition
+  __device__ __forceinline__ uint2 prefetchGroup(uint32_t, uint32_t) const { return make_uint2(0, 0); }
+  __device__ __forceinline__ void stageRow(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t) const {}
+  __device__ __forceinline__ void flushGroup(uint32_t, uint32_t, uint32_t) const {}
 };
 
 // ---------------------------------------------------------------------------
@@ -141,12 +195,23 @@ constexpr uint32_t kDecBlocksPerTile = 16;
 // a 16-block workgroup would leave most of its waves without a block while
 // still holding its LDS and wave slots.
 constexpr uint32_t kDecBlocksPerSmallTile = 4;
-__host__ __device__ constexpr uint32_t decLdsBytes(int P, uint32_t tileBlocks) {
-  return (8u << P) + tileBlocks * kRingBytes;
+// Wide loads of the non-compressed bytes (16-bit float types, together with the wide stores): the 256 bytes
+// of a group fetched with one 8-byte load per lane and spread through a second LDS buffer.  Measured 3.7 us
+// SLOWER per step than the 1-byte loads (241 vs 237 us, 5 interleaved runs): off, kept as an A/B knob.
+#ifndef DGPU_DEC_WIDE_LOADS
+#define DGPU_DEC_WIDE_LOADS 0
+#endif
+__host__ __device__ constexpr bool decWideLoads(uint32_t ft) { return DGPU_DEC_WIDE_LOADS && (ft == kFloat16 || ft == kBFloat16); }
+__host__ __device__ constexpr uint32_t decXposeBytes(int P, uint32_t ft) {
+  return (DGPU_DEC_WIDE_STORES && P <= 10) ? (ft == kFloat32 ? 0u : ft == 0 ? 256u : 512u + (decWideLoads(ft) ? 256u : 0u)) : 0u;
+}
+__host__ __device__ constexpr uint32_t decLdsBytes(int P, uint32_t ft, uint32_t tileBlocks) {
+  return (8u << P) + tileBlocks * kRingBytes + tileBlocks * decXposeBytes(P, ft);
 }
 
-template <int P, uint32_t FT, bool kFull>
+template <int P, uint32_t FT, bool kFull, bool kWide = false>
 __device__ __forceinline__ void decodeBlock(
+    uint32_t xpose,                // kWide: LDS address of this half's transposition buffer
     uint32_t state,
     uint32_t n,                    // symbols in this half's block (0 = idle half)
     uint32_t groups,               // wave-uniform number of 8-row groups to run
@@ -219,19 +284,34 @@ __device__ __forceinline__ void decodeBlock(
   // vmcnt waits instead of draining the memory queue every group.
   uint32_t preCur[kGroupRows], preNext[kGroupRows];
   const int lastGroup = (int)groups - 1;
+  constexpr bool kWideNc = kFull && kWide && decWideLoads(FT);
+  const uint32_t xposeNc = xpose + 512u;  // second buffer (kWideNc)
+  uint2 ncCur = make_uint2(0, 0), ncNext = make_uint2(0, 0);
+  if (kWideNc) ncCur = sink.prefetchGroup((uint32_t)lastGroup, hl);
 #pragma unroll
   for (int j = 0; j < (int)kGroupRows; ++j) {
     const uint32_t row = (uint32_t)lastGroup * kGroupRows + j;
-    preCur[j] = (kFull || row * 32u + hl < n) ? sink.prefetch(row) : 0u;
+    preCur[j] = kWideNc ? 0u : ((kFull || row * 32u + hl < n) ? sink.prefetch(row) : 0u);
   }
 
 #pragma unroll 1
   for (int g = lastGroup; g >= 0; --g) {
     const uint32_t gNext = g > 0 ? (uint32_t)(g - 1) : 0u;
+    if (kWideNc) {
+      ncNext = sink.prefetchGroup(gNext, hl);
+      // this group's 256 bytes: lane hl holds bytes [8 hl, 8 hl + 8); row j wants byte 32 j + hl
+      typedef uint32_t u32x2n __attribute__((ext_vector_type(2)));
+      *(__attribute__((address_space(3))) u32x2n*)(uintptr_t)(xposeNc + hl * 8u) = u32x2n{ncCur.x, ncCur.y};
 #pragma unroll
-    for (int j = 0; j < (int)kGroupRows; ++j) {
-      const uint32_t row = gNext * kGroupRows + j;
-      preNext[j] = (kFull || row * 32u + hl < n) ? sink.prefetch(row) : 0u;
+      for (int j = 0; j < (int)kGroupRows; ++j) {
+        preCur[j] = *(const __attribute__((address_space(3))) uint8_t*)(uintptr_t)(xposeNc + (uint32_t)j * 32u + hl);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < (int)kGroupRows; ++j) {
+        const uint32_t row = gNext * kGroupRows + j;
+        preNext[j] = (kFull || row * 32u + hl < n) ? sink.prefetch(row) : 0u;
+      }
     }
     // ring maintenance
     if (pendingChunk >= 0) {
@@ -249,15 +329,21 @@ __device__ __forceinline__ void decodeBlock(
       const uint32_t row = (uint32_t)g * kGroupRows + j;
       if (kFull) {
         const uint32_t e0 = stepFull();
-        sink.store(row, e0, preCur[j]);
+        if (kWide) sink.stageRow(xpose, (uint32_t)j, hl, e0, preCur[j]);
+        else sink.store(row, e0, preCur[j]);
       } else {
         const bool valid = row * 32u + hl < n;
         const uint32_t e0 = step(valid);
         if (valid) sink.store(row, e0, preCur[j]);
       }
     }
+    if (kFull && kWide) sink.flushGroup(xpose, (uint32_t)g, hl);
+    if (kWideNc) {
+      ncCur = ncNext;
+    } else {
 #pragma unroll
-    for (int j = 0; j < (int)kGroupRows; ++j) preCur[j] = preNext[j];
+      for (int j = 0; j < (int)kGroupRows; ++j) preCur[j] = preNext[j];
+    }
   }
 }
 
@@ -266,8 +352,9 @@ template <int P, uint32_t FT, uint32_t kTileBlocks>
 __global__ __launch_bounds__(kTileBlocks * 32u) void k_ans_decode(DecodeArgs a) {
   constexpr uint32_t kDecThreads = kTileBlocks * 32u;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  // rings: 16 x 2 KiB at LDS offset 0 (2 KiB aligned), then the LUT
+  // rings: 16 x 2 KiB at LDS offset 0 (2 KiB aligned), then the LUT, then the transposition buffers
   uint2* sLut = (uint2*)(smem + kTileBlocks * kRingBytes);
+  constexpr uint32_t kXpose = decXposeBytes(P, FT);
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
@@ -419,11 +506,17 @@ __global__ __launch_bounds__(kTileBlocks * 32u) void k_ans_decode(DecodeArgs a) 
   // uniform per wave: both halves hold full blocks?
   const uint32_t nFirst = __shfl(n, 0, 64);
   const uint32_t nSecond = __shfl(n, 32, 64);
+  const uint32_t xpose = ldsBase + kTileBlocks * kRingBytes + (8u << P) + hw * kXpose;
   if (nFirst == kBlockSize && nSecond == kBlockSize) {
-    decodeBlock<P, FT, true>(state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
+    // wide stores need a 16-byte aligned output element (uniform per workgroup)
+    if (kXpose != 0 && (((uintptr_t)a.out.ptr(b)) & 15u) == 0) {
+      decodeBlock<P, FT, true, true>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
+    } else {
+      decodeBlock<P, FT, true>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
+    }
   } else {
     const uint32_t maxN = nFirst > nSecond ? nFirst : nSecond;
-    decodeBlock<P, FT, false>(state, n, divUp(divUp(maxN, 32u), kGroupRows), gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
+    decodeBlock<P, FT, false>(xpose, state, n, divUp(divUp(maxN, 32u), kGroupRows), gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
   }
 }
 
