@@ -194,7 +194,7 @@ def baseline_metric():
 def measured_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (cannot be collected inside this
     process: rocprofv3 wraps the command).  None when no pass exists for this workload."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
     try:
         with open(path) as f:
             rec = json.load(f)["workloads"][workload][kernel]
@@ -421,7 +421,7 @@ def main():
                 "traffic": measured_traffic(args.workload, dom) if (args.batch == 256 and args.elems == 512 * 1024) else None,
                 "avg_us": kernels[dom]["avg_us"],
                 "algorithmic_bytes": algorithmic_bytes(dom, codec, comp_total),
-                "traffic_source": "profiles/r01_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                "traffic_source": "profiles/r02_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                   "(tools/gpu_pmc.sh), (2*FETCH_SIZE + WRITE_SIZE) KiB per launch",
             }
         # whole-step figure: algorithmic bytes of encode + decode over the step time
