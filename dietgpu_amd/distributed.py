@@ -75,19 +75,23 @@ def max_over_ranks(seconds, device):
 # is bound by one link per hop, so the bytes saved by the codec (x0.67 for bf16
 # gradients/activations) translate directly into collective time.
 class GpuFloatCodec:
-    """Default codec of compressed_all_gather: the HIP float codec (torch tensors on the GPU)."""
+    """Default codec of the compressed collectives: the HIP float codec through `torch.ops.dietgpu.*`
+    (csrc/torch_ops.cpp over the C ABI: no per-call Python marshalling of pointer arrays).  `temp_mem`
+    (optional uint8 tensor) is handed to every call, as the reference's ops take it."""
+
+    def __init__(self, temp_mem=None):
+        from . import load_torch_ops
+
+        self.ops = load_torch_ops()
+        self.temp_mem = temp_mem
 
     def compress(self, tensors):
-        from . import ops
-
-        comp, sizes, _ = ops.compress_data(True, tensors, False, None)
+        comp, sizes, _ = self.ops.compress_data(True, tensors, False, self.temp_mem)
         return comp, sizes
 
     def decompress(self, rows, outs):
-        from . import ops
-
         status = torch.zeros((len(rows),), dtype=torch.uint8, device=outs[0].device)
-        ops.decompress_data(True, rows, outs, False, None, status, None)
+        self.ops.decompress_data(True, rows, outs, False, self.temp_mem, status, None)
         return status
 
 
@@ -133,3 +137,102 @@ def compressed_all_gather(tensors, codec=None):
         "payload_bytes": int(all_sizes[dist.get_rank()].sum().item()),
     }
     return gathered, stats
+
+
+# ---------------------------------------------------------------------------
+# Pipelined compressed all-gather: no host synchronisation between the phases, compression of chunk
+# k + 1 overlapped with the exchange of chunk k (and with the decompression of chunk k - 1).
+#
+#   * rows are exchanged at a FIXED width W = width_fraction x the raw row bytes (rounded up to 16), so the
+#     payload collective's shape is known on the host without reading the compressed sizes back.  bf16 / fp16
+#     activations and gradients compress to ~0.67 (README.md:45-60 of the reference); the default 0.75
+#     leaves headroom.  A row that does not fit is detected from the all-gathered sizes ON THE DEVICE;
+#   * the only host synchronisation is ONE read of the "some row overflowed" flag at the very end; if it
+#     is set (incompressible data) the affected chunks are gathered again uncompressed;
+#   * streams: compress on `comp_stream`; every collective is asynchronous (RCCL runs it on its own
+#     stream, ordered after the compress stream at the call); decompress on `dec_stream` after the
+#     work handle.  On CPU tensors (gloo, the unit tests) everything degenerates to in-order execution.
+def compressed_all_gather_pipelined(tensors, chunks=4, width_fraction=0.75, codec=None):
+    """All-gathers a list of equally-shaped float tensors per rank, moving compressed bytes.
+
+    Returns (gathered, stats): gathered[r][i] is rank r's i-th tensor, bit-exact;
+    stats = {"raw_bytes", "wire_bytes", "overflow_chunks"} per rank-to-rank copy."""
+    codec = codec or GpuFloatCodec()
+    world = dist.get_world_size()
+    n = len(tensors)
+    dev = tensors[0].device
+    on_gpu = dev.type == "cuda"
+    row_bytes = tensors[0].numel() * tensors[0].element_size()
+    assert all(t.shape == tensors[0].shape and t.dtype == tensors[0].dtype for t in tensors)
+    # archive = 16-byte float header + non-compressed plane + ANS archive; W must at least hold the overhead
+    width = (int(row_bytes * width_fraction) + 15) // 16 * 16
+    bounds = [shard_range(n, k, min(chunks, n)) for k in range(min(chunks, n))]
+
+    cur = torch.cuda.current_stream(dev) if on_gpu else None
+    comp_stream = torch.cuda.Stream(dev) if on_gpu else None
+    dec_stream = torch.cuda.Stream(dev) if on_gpu else None
+    if on_gpu:
+        comp_stream.wait_stream(cur)  # the inputs were produced on the caller's stream
+        dec_stream.wait_stream(cur)
+
+    def on(stream):
+        return torch.cuda.stream(stream) if on_gpu else _NullContext()
+
+    pending = []   # (chunk index, payload work, sizes work, gathered payloads, gathered sizes)
+    keep = []      # buffers RCCL may still be reading
+    for k, (lo, hi) in enumerate(bounds):
+        with on(comp_stream):
+            comp, sizes = codec.compress(tensors[lo:hi])
+            sizes = sizes.to(torch.int32)
+            w = min(width, comp.shape[1])
+            payload = comp[:, :w].contiguous()
+            gp = [torch.empty_like(payload) for _ in range(world)]
+            gs = [torch.empty_like(sizes) for _ in range(world)]
+            wp = dist.all_gather(gp, payload, async_op=True)
+            ws = dist.all_gather(gs, sizes, async_op=True)
+            keep.append((comp, payload, sizes))
+        pending.append((k, w, wp, ws, gp, gs))
+
+    gathered = [[None] * n for _ in range(world)]
+    overflow_flags = []
+    for k, w, wp, ws, gp, gs in pending:
+        lo, hi = bounds[k]
+        with on(dec_stream):
+            wp.wait()
+            ws.wait()
+            all_sizes = torch.stack(gs)                      # [world, rows] on the device
+            overflow_flags.append((all_sizes > w).any())     # stays on the device
+            for r in range(world):
+                rows = [gp[r][i] for i in range(hi - lo)]    # fixed-width rows; the archives say how long they are
+                outs = [torch.empty_like(t) for t in tensors[lo:hi]]
+                codec.decompress(rows, outs)
+                gathered[r][lo:hi] = outs
+    if on_gpu:
+        cur.wait_stream(dec_stream)
+        cur.wait_stream(comp_stream)
+
+    # the one host synchronisation: did any row not fit into the fixed width?
+    flags = torch.stack(overflow_flags).to("cpu")
+    redo = [k for k in range(len(bounds)) if bool(flags[k])]
+    for k in redo:
+        lo, hi = bounds[k]
+        raw = torch.stack([t.reshape(-1) for t in tensors[lo:hi]])
+        got = [torch.empty_like(raw) for _ in range(world)]
+        dist.all_gather(got, raw)
+        for r in range(world):
+            gathered[r][lo:hi] = [got[r][i].reshape(tensors[lo + i].shape) for i in range(hi - lo)]
+    stats = {
+        "raw_bytes": n * row_bytes,
+        "wire_bytes": n * min(width, keep[0][0].shape[1]) + sum((hi - lo) * row_bytes for lo, hi in (bounds[k] for k in redo)),
+        "overflow_chunks": len(redo),
+        "chunks": len(bounds),
+    }
+    return gathered, stats
+
+
+class _NullContext:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

@@ -41,3 +41,52 @@ def test_compressed_all_gather_single_rank_rccl():
         assert stats["wire_bytes"] < 0.80 * stats["raw_bytes"]
     finally:
         dist.destroy_process_group()
+
+
+def test_pipelined_compressed_all_gather_single_rank_rccl():
+    # fixed-width rows, no host synchronisation between phases, compress / exchange / decompress on
+    # separate streams, through torch.ops.dietgpu.* (one-rank RCCL group: the box has one GPU)
+    import torch.distributed as dist
+
+    import dietgpu_amd
+    from dietgpu_amd import distributed as D
+
+    dietgpu_amd.lib()
+    os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    D.init(backend="nccl", device=dev)
+    try:
+        g = torch.Generator(device="cpu").manual_seed(11)
+        mine = [torch.randn(262144, generator=g).to(torch.bfloat16).to(dev) for _ in range(13)]
+        gathered, stats = D.compressed_all_gather_pipelined(mine, chunks=4)
+        assert stats["overflow_chunks"] == 0 and stats["wire_bytes"] <= 0.76 * stats["raw_bytes"]
+        for a, b in zip(gathered[0], mine):
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+        # incompressible rows do not fit the fixed width: detected on the device, gathered again uncompressed
+        noise = [torch.randint(-32768, 32767, (65536,), generator=g, dtype=torch.int16).to(dev).view(torch.bfloat16)
+                 for _ in range(5)]
+        gathered, stats = D.compressed_all_gather_pipelined(noise, chunks=2)
+        assert stats["overflow_chunks"] == 2
+        for a, b in zip(gathered[0], noise):
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_collective_mode_two_ranks_one_device():
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DGPU_BENCH_ONE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
+                        "--collective", "--steps", "2", "--warmup", "1", "--batch", "16"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["bit_exact"] and d["config"]["overflow_chunks"] == 0
+    assert d["config"]["wire_bytes_per_rank"] < d["config"]["per_rank_bytes"]
