@@ -277,9 +277,7 @@ def run_collective(args, data, ft, desc, world, rank, device, D):
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         D.init(backend=args.dist_backend, device=device)
-    rows = list(data.unbind(0))
     raw_bytes = data.numel() * data.element_size()
-    codec = D.GpuFloatCodec(temp_mem=torch.empty((256 << 20,), dtype=torch.uint8, device=device))
 
     def fence():
         torch.cuda.synchronize()
@@ -291,8 +289,11 @@ def run_collective(args, data, ft, desc, world, rank, device, D):
         dist.all_gather(out, data)
         return out
 
+    plan = D.CompressedAllGatherPlan(data, chunks=args.chunks)
+
     def compressed():
-        return D.compressed_all_gather_pipelined(rows, chunks=args.chunks, codec=codec)
+        out, redo = plan.run(data)
+        return out, {"wire_bytes": plan.wire_bytes, "overflow_chunks": redo}
 
     def timed(fn):
         for _ in range(args.warmup):
@@ -308,7 +309,7 @@ def run_collective(args, data, ft, desc, world, rank, device, D):
     t_comp, (got_comp, stats) = timed(compressed)
     view = torch.int32 if ft == 3 else torch.int16
     for r in range(world):
-        assert torch.equal(torch.stack(got_comp[r]).view(view), got_plain[r].view(view)), "compressed all-gather is not bit-exact"
+        assert torch.equal(got_comp[r].view(view), got_plain[r].view(view)), "compressed all-gather is not bit-exact"
     if rank == 0:
         recv = (world - 1) * raw_bytes if world > 1 else raw_bytes  # bytes of other ranks' tensors each rank ends up with
         print(json.dumps({
@@ -346,7 +347,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--collective", action="store_true",
                     help="instead of the codec step: plain vs compressed all-gather of every rank's shard "
-                         "(dietgpu_amd.distributed.compressed_all_gather_pipelined), effective GB/s per rank")
+                         "(dietgpu_amd.distributed.CompressedAllGatherPlan), effective GB/s per rank")
     ap.add_argument("--chunks", type=int, default=4, help="--collective: pipeline chunks per shard")
     ap.add_argument("--timeline", action="store_true",
                     help="only the timed steps (no per-phase timing / kernel profile): for rocprofv3 timelines")

@@ -63,6 +63,14 @@ def test_pipelined_compressed_all_gather_single_rank_rccl():
         assert stats["overflow_chunks"] == 0 and stats["wire_bytes"] <= 0.76 * stats["raw_bytes"]
         for a, b in zip(gathered[0], mine):
             assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+        # the reusable plan (what bench.py --collective times): C ABI calls on prebuilt pointer arrays
+        shard = torch.stack(mine)
+        plan = D.CompressedAllGatherPlan(shard, chunks=3)
+        for _ in range(3):
+            out, redo = plan.run(shard)
+            torch.cuda.synchronize()
+            assert redo == 0 and torch.equal(out[0].view(torch.int16), shard.view(torch.int16))
+        assert bool(plan.status.all())
         # incompressible rows do not fit the fixed width: detected on the device, gathered again uncompressed
         noise = [torch.randint(-32768, 32767, (65536,), generator=g, dtype=torch.int16).to(dev).view(torch.bfloat16)
                  for _ in range(5)]
@@ -70,6 +78,10 @@ def test_pipelined_compressed_all_gather_single_rank_rccl():
         assert stats["overflow_chunks"] == 2
         for a, b in zip(gathered[0], noise):
             assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+        nshard = torch.stack(noise)
+        out, redo = D.CompressedAllGatherPlan(nshard, chunks=2).run(nshard)
+        torch.cuda.synchronize()
+        assert redo == 2 and torch.equal(out[0].view(torch.int16), nshard.view(torch.int16))
     finally:
         dist.destroy_process_group()
 
