@@ -613,6 +613,7 @@ struct DeviceBatch {
 struct HostParams {
   std::vector<uint64_t> inPtrs, outPtrs;
   std::vector<uint32_t> sizes;
+  std::vector<uint32_t> inBytes;  // decode, *_bounded entry points: bytes available per compressed input
 };
 
 // uniform size (0 if the sizes differ) and 16-byte alignment of every input pointer of a pointer batch
@@ -632,9 +633,10 @@ void batchShape(const HostParams& hp, uint32_t* uniformSize, bool* aligned16) {
 
 int uploadParams(
     ParamLease& lease, hipStream_t stream, const HostParams& hp,
-    const uint64_t** inPtrs_dev, const uint64_t** outPtrs_dev, const uint32_t** sizes_dev) {
-  const size_t nIn = hp.inPtrs.size(), nOut = hp.outPtrs.size(), nSz = hp.sizes.size();
-  const size_t bytes = (nIn + nOut) * 8 + alignUp(nSz * 4, 8);
+    const uint64_t** inPtrs_dev, const uint64_t** outPtrs_dev, const uint32_t** sizes_dev,
+    const uint32_t** inBytes_dev = nullptr) {
+  const size_t nIn = hp.inPtrs.size(), nOut = hp.outPtrs.size(), nSz = hp.sizes.size(), nIb = hp.inBytes.size();
+  const size_t bytes = (nIn + nOut) * 8 + alignUp(nSz * 4, 8) + alignUp(nIb * 4, 8);
   if (bytes == 0) return DGPU_OK;
   static thread_local std::vector<uint8_t> block;
   block.assign(bytes, 0);
@@ -642,6 +644,7 @@ int uploadParams(
   if (nIn) memcpy(h, hp.inPtrs.data(), nIn * 8);
   if (nOut) memcpy(h + nIn * 8, hp.outPtrs.data(), nOut * 8);
   if (nSz) memcpy(h + (nIn + nOut) * 8, hp.sizes.data(), nSz * 4);
+  if (nIb) memcpy(h + (nIn + nOut) * 8 + alignUp(nSz * 4, 8), hp.inBytes.data(), nIb * 4);
   ParamCache::Entry* entry = nullptr;
   bool miss = false;
   DGPU_HIP(paramCache().acquire(h, bytes, stream, &entry, &miss));
@@ -650,6 +653,7 @@ int uploadParams(
   *inPtrs_dev = nIn ? (const uint64_t*)dev : nullptr;
   *outPtrs_dev = nOut ? (const uint64_t*)(dev + nIn * 8) : nullptr;
   *sizes_dev = nSz ? (const uint32_t*)(dev + (nIn + nOut) * 8) : nullptr;
+  if (inBytes_dev) *inBytes_dev = nIb ? (const uint32_t*)(dev + (nIn + nOut) * 8 + alignUp(nSz * 4, 8)) : nullptr;
   return DGPU_OK;
 }
 
@@ -1157,10 +1161,11 @@ int decodeImpl(
   TempArena arena(temp_dev, tempBytes, streamLease);
   ParamLease lease;
   BatchView in, out;
+  const uint32_t* inBytes_dev = nullptr;
   if (hp) {
     const uint64_t *inP = nullptr, *outP = nullptr;
     const uint32_t* cap = nullptr;
-    int rc = uploadParams(lease, stream, *hp, &inP, &outP, &cap);
+    int rc = uploadParams(lease, stream, *hp, &inP, &outP, &cap, &inBytes_dev);
     if (rc) return rc;
     in = viewPointers(inP, nullptr, 0);
     out = viewPointers(outP, cap, 0);
@@ -1193,6 +1198,7 @@ int decodeImpl(
     d.floatType = ft;
     d.outSuccess = useChecksum ? successForChecksum : outSuccess_dev;
     d.outSize = useChecksum ? sizesForChecksum : outSize_dev;
+    d.inBytes = inBytes_dev;
     dim3 grid(maxTiles, B);
     int rc;
     if (ft == 0) rc = launchDecodeF<0>(P, d, tileBlocks, grid, stream);
@@ -1467,11 +1473,12 @@ static int decodePointerCommon(
     void* temp_dev, size_t tempBytes, size_t* tempUsed, uint32_t ft, int probBits,
     int useChecksum, uint32_t numInBatch, const void* const* in, void* const* out,
     const uint32_t* outCapacity, uint8_t* outSuccess_dev, uint32_t* outSize_dev, void* stream,
-    int32_t* errBatch) {
+    int32_t* errBatch, const uint32_t* inBytes = nullptr) {
   HostParams hp;
   hp.inPtrs.resize(numInBatch);
   hp.outPtrs.resize(numInBatch);
   hp.sizes.resize(numInBatch);
+  if (inBytes) hp.inBytes.assign(inBytes, inBytes + numInBatch);
   uint32_t maxCap = 0;
   for (uint32_t i = 0; i < numInBatch; ++i) {
     DGPU_REQUIRE(((uintptr_t)in[i] % 16) == 0, "compressed input must be 16-byte aligned");
@@ -1497,8 +1504,9 @@ static int decodeSplitCommon(
     void* temp_dev, size_t tempBytes, size_t* tempUsed, uint32_t ft, int probBits,
     int useChecksum, uint32_t numInBatch, const void* const* in, void* out_dev,
     const uint32_t* outSplitSizes, uint8_t* outSuccess_dev, uint32_t* outSize_dev, void* stream,
-    int32_t* errBatch) {
+    int32_t* errBatch, const uint32_t* inBytes = nullptr) {
   HostParams hp;
+  if (inBytes) hp.inBytes.assign(inBytes, inBytes + numInBatch);
   uint32_t maxCap = 0;
   splitSizesToPointers(out_dev, outSplitSizes, numInBatch, ft ? floatWordBytes(ft) : 1u,
                        &hp.outPtrs, &hp.sizes, &maxCap);
@@ -1523,6 +1531,45 @@ int dgpu_ans_decode_batch_split_size(
   }
   return decodeSplitCommon(temp_dev, tempBytes, tempUsed, 0, probBits, useChecksum, numInBatch, in,
                            out_dev, outSplitSizes, outSuccess_dev, outSize_dev, stream, errBatch);
+}
+
+// ---- decode with known input sizes ("bounded") ---------------------------------
+// Same as the four pointer / split-size decode entry points, plus `inBytes` (HOST array): the bytes available at
+// in[i].  The reference API carries no compressed sizes, so a truncated archive is followed past its buffer
+// there; the tensor API knows every tensor's size and uses these.
+int dgpu_ans_decode_batch_pointer_bounded(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, int probBits, int useChecksum,
+    uint32_t numInBatch, const void* const* in, const uint32_t* inBytes, void* const* out,
+    const uint32_t* outCapacity, uint8_t* outSuccess_dev, uint32_t* outSize_dev, void* stream, int32_t* errBatch) {
+  return decodePointerCommon(temp_dev, tempBytes, tempUsed, 0, probBits, useChecksum, numInBatch, in, out, outCapacity,
+                             outSuccess_dev, outSize_dev, stream, errBatch, inBytes);
+}
+int dgpu_ans_decode_batch_split_size_bounded(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, int probBits, int useChecksum,
+    uint32_t numInBatch, const void* const* in, const uint32_t* inBytes, void* out_dev,
+    const uint32_t* outSplitSizes, uint8_t* outSuccess_dev, uint32_t* outSize_dev, void* stream, int32_t* errBatch) {
+  DGPU_REQUIRE(((uintptr_t)out_dev % DGPU_ANS_REQUIRED_ALIGNMENT) == 0, "output must be 4-byte aligned");
+  for (uint32_t i = 0; i + 1 < numInBatch; ++i) {
+    DGPU_REQUIRE(outSplitSizes[i] % DGPU_ANS_REQUIRED_ALIGNMENT == 0, "interior split sizes must be multiples of 4 bytes");
+  }
+  return decodeSplitCommon(temp_dev, tempBytes, tempUsed, 0, probBits, useChecksum, numInBatch, in, out_dev,
+                           outSplitSizes, outSuccess_dev, outSize_dev, stream, errBatch, inBytes);
+}
+int dgpu_float_decompress_bounded(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, uint32_t floatType, int probBits, int useChecksum,
+    uint32_t numInBatch, const void* const* in, const uint32_t* inBytes, void* const* out,
+    const uint32_t* outCapacity, uint8_t* outSuccess_dev, uint32_t* outSize_dev, void* stream, int32_t* errBatch) {
+  DGPU_REQUIRE(validFloatType(floatType), "floatType must be float16, bfloat16 or float32");
+  return decodePointerCommon(temp_dev, tempBytes, tempUsed, floatType, probBits, useChecksum, numInBatch, in, out,
+                             outCapacity, outSuccess_dev, outSize_dev, stream, errBatch, inBytes);
+}
+int dgpu_float_decompress_split_size_bounded(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, uint32_t floatType, int probBits, int useChecksum,
+    uint32_t numInBatch, const void* const* in, const uint32_t* inBytes, void* out_dev,
+    const uint32_t* outSplitSizes, uint8_t* outSuccess_dev, uint32_t* outSize_dev, void* stream, int32_t* errBatch) {
+  DGPU_REQUIRE(validFloatType(floatType), "floatType must be float16, bfloat16 or float32");
+  return decodeSplitCommon(temp_dev, tempBytes, tempUsed, floatType, probBits, useChecksum, numInBatch, in, out_dev,
+                           outSplitSizes, outSuccess_dev, outSize_dev, stream, errBatch, inBytes);
 }
 
 // ---- info ------------------------------------------------------------------

@@ -44,6 +44,8 @@ struct DecodeArgs {
   uint32_t floatType;      // must equal the template FT
   uint8_t* outSuccess;     // [B] nullable
   uint32_t* outSize;       // [B] nullable
+  const uint32_t* inBytes; // [B] nullable: bytes available at in.ptr(b) (the *_bounded entry points); an archive
+                           // that claims to be longer is rejected instead of being read past its buffer
 };
 
 // ---------------------------------------------------------------------------
@@ -367,12 +369,21 @@ __global__ __launch_bounds__(kTileBlocks * 32u) void k_ans_decode(DecodeArgs a) 
 
   const uint8_t* archive = a.in.ptr(b);
   uint32_t floatSize = 0;
+  const uint64_t inBytes = a.inBytes ? (uint64_t)a.inBytes[b] : ~0ull;
+  if (inBytes < (FT ? sizeof(FloatHeader) : sizeof(AnsHeader))) {  // uniform: not even a header
+    if (tile == 0 && tid == 0) {
+      if (a.outSuccess) a.outSuccess[b] = 0;
+      if (a.outSize) a.outSize[b] = 0;
+    }
+    return;
+  }
   if (FT) {
     // the float header locates the ANS archive: check it before following it
     // (GpuFloatHeader::checkMagicAndVersion / getFloatType asserts, GpuFloatUtils.cuh:31-41, GpuFloatDecompress.cuh:332-382)
     const FloatHeader fh = *(const FloatHeader*)archive;
     const bool fhOk = fh.magicAndVersion == ((kFloatMagic << 16) | kFloatVersion) && (fh.options & 0xfu) == FT &&
-        fh.size <= a.out.size(b);
+        fh.size <= a.out.size(b) &&
+        (uint64_t)sizeof(FloatHeader) + floatUncompDataSize(FT, fh.size) + sizeof(AnsHeader) <= inBytes;
     if (!fhOk) {  // uniform
       if (tile == 0 && tid == 0) {
         if (a.outSuccess) a.outSuccess[b] = 0;
@@ -400,6 +411,8 @@ __global__ __launch_bounds__(kTileBlocks * 32u) void k_ans_decode(DecodeArgs a) 
       (header.options & 0xfu) == (uint32_t)P;
   if (FT) success = success && floatSize == total;
   success = success && nb == divUp(total, kBlockSize);
+  // the archive as a whole fits the bytes the caller has (when told)
+  success = success && (uint64_t)ansOffsetInArchive(FT, total) + ansOverhead(nb) + 2ull * totalWords <= inBytes;
   if (!success) {  // uniform: nothing else of the archive is read
     if (tile == 0 && tid == 0) {
       if (a.outSuccess) a.outSuccess[b] = 0;

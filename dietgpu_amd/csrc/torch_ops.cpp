@@ -280,6 +280,7 @@ int64_t decompress_data_impl(
   std::vector<const void*> inPtrs(n);
   std::vector<void*> outPtrs(n);
   std::vector<uint32_t> outCapacity(n);
+  std::vector<uint32_t> inBytes(n);  // the tensors say how many bytes each archive may occupy
   for (size_t i = 0; i < n; ++i) {
     auto& tIn = tIns[i];
     auto& tOut = tOuts[i];
@@ -292,6 +293,7 @@ int64_t decompress_data_impl(
     TORCH_CHECK(tIn.dtype() == at::kByte);
     if (compressAsFloat) floatTypeFromDtype(tOut.scalar_type());
     inPtrs[i] = tIn.data_ptr();
+    inBytes[i] = (uint32_t)std::min<int64_t>(tIn.numel(), std::numeric_limits<uint32_t>::max());
     outPtrs[i] = tOut.data_ptr();
     auto cap = compressAsFloat ? tOut.numel() : tOut.numel() * tOut.element_size();
     TORCH_CHECK((uint64_t)cap <= std::numeric_limits<uint32_t>::max());
@@ -301,14 +303,14 @@ int64_t decompress_data_impl(
   size_t used = 0;
   int32_t err = -1;
   if (compressAsFloat) {
-    check(dgpu_float_decompress(tmp.ptr, tmp.bytes, &used, floatTypeFromDtype(tOuts[0].scalar_type()), kDefaultPrecision,
-                                checksum, (uint32_t)n, inPtrs.data(), outPtrs.data(), outCapacity.data(),
+    check(dgpu_float_decompress_bounded(tmp.ptr, tmp.bytes, &used, floatTypeFromDtype(tOuts[0].scalar_type()), kDefaultPrecision,
+                                checksum, (uint32_t)n, inPtrs.data(), inBytes.data(), outPtrs.data(), outCapacity.data(),
                                 outStatus ? (uint8_t*)outStatus->data_ptr() : nullptr,
                                 outSizes ? (uint32_t*)outSizes->data_ptr() : nullptr, streamOf(dev), &err),
           "floatDecompress", true);
   } else {
-    check(dgpu_ans_decode_batch_pointer(tmp.ptr, tmp.bytes, &used, kDefaultPrecision, checksum, (uint32_t)n,
-                                        inPtrs.data(), outPtrs.data(), outCapacity.data(),
+    check(dgpu_ans_decode_batch_pointer_bounded(tmp.ptr, tmp.bytes, &used, kDefaultPrecision, checksum, (uint32_t)n,
+                                        inPtrs.data(), inBytes.data(), outPtrs.data(), outCapacity.data(),
                                         outStatus ? (uint8_t*)outStatus->data_ptr() : nullptr,
                                         outSizes ? (uint32_t*)outSizes->data_ptr() : nullptr, streamOf(dev), &err),
           "ansDecodeBatchPointer", false);
@@ -340,6 +342,7 @@ int64_t decompress_data_split_size(
   TORCH_CHECK(numInBatch == (int64_t)tIns.size());
   std::vector<const void*> inPtrs(numInBatch);
   std::vector<uint32_t> splitSizes(numInBatch);
+  std::vector<uint32_t> inBytes(numInBatch);
   for (int64_t i = 0; i < numInBatch; ++i) {
     auto& tIn = tIns[i];
     TORCH_CHECK(tIn.device().is_cuda());
@@ -347,6 +350,7 @@ int64_t decompress_data_split_size(
     TORCH_CHECK(tIn.is_contiguous());
     TORCH_CHECK(tIn.dtype() == at::kByte);
     inPtrs[i] = tIn.data_ptr();
+    inBytes[i] = (uint32_t)std::min<int64_t>(tIn.numel(), std::numeric_limits<uint32_t>::max());
     auto size = ((const int32_t*)tSplitSizes.data_ptr())[i];
     TORCH_CHECK(size > 0);
     splitSizes[i] = size;
@@ -359,15 +363,15 @@ int64_t decompress_data_split_size(
   size_t used = 0;
   int32_t err = -1;
   if (compressAsFloat) {
-    check(dgpu_float_decompress_split_size(tmp.ptr, tmp.bytes, &used, floatTypeFromDtype(tOut.scalar_type()),
-                                           kDefaultPrecision, checksum, (uint32_t)numInBatch, inPtrs.data(),
+    check(dgpu_float_decompress_split_size_bounded(tmp.ptr, tmp.bytes, &used, floatTypeFromDtype(tOut.scalar_type()),
+                                           kDefaultPrecision, checksum, (uint32_t)numInBatch, inPtrs.data(), inBytes.data(),
                                            tOut.data_ptr(), splitSizes.data(),
                                            outStatus ? (uint8_t*)outStatus->data_ptr() : nullptr,
                                            outSizes ? (uint32_t*)outSizes->data_ptr() : nullptr, streamOf(dev), &err),
           "floatDecompressSplitSize", true);
   } else {
-    check(dgpu_ans_decode_batch_split_size(tmp.ptr, tmp.bytes, &used, kDefaultPrecision, checksum, (uint32_t)numInBatch,
-                                           inPtrs.data(), tOut.data_ptr(), splitSizes.data(),
+    check(dgpu_ans_decode_batch_split_size_bounded(tmp.ptr, tmp.bytes, &used, kDefaultPrecision, checksum, (uint32_t)numInBatch,
+                                           inPtrs.data(), inBytes.data(), tOut.data_ptr(), splitSizes.data(),
                                            outStatus ? (uint8_t*)outStatus->data_ptr() : nullptr,
                                            outSizes ? (uint32_t*)outSizes->data_ptr() : nullptr, streamOf(dev), &err),
           "ansDecodeBatchSplitSize", false);

@@ -61,6 +61,11 @@ def _u32_array(vals):
     return (C.c_uint32 * len(vals))(*vals)
 
 
+def _in_bytes(ts):
+    """bytes each compressed input tensor holds: the decoder rejects an archive that claims more"""
+    return (C.c_uint32 * len(ts))(*[min(t.numel() * t.element_size(), _U32_MAX) for t in ts])
+
+
 def _temp(temp_mem, dev):
     if temp_mem is None:
         return None, 0
@@ -232,13 +237,13 @@ def decompress_data(compress_as_float, ts_in, ts_out, checksum=False, temp_mem=N
         used = C.c_size_t(0)
         err = C.c_int32(-1)
         if compress_as_float:
-            rc = lib().dgpu_float_decompress(
+            rc = lib().dgpu_float_decompress_bounded(
                 tp, tb, C.byref(used), _float_type(ts_out[0]), prob_bits, int(checksum), n,
-                _ptr_array(ts_in), _ptr_array(ts_out), _u32_array(caps), _ptr(out_status),
+                _ptr_array(ts_in), _in_bytes(ts_in), _ptr_array(ts_out), _u32_array(caps), _ptr(out_status),
                 _ptr(out_decompressed_words), _stream(), C.byref(err))
         else:
-            rc = lib().dgpu_ans_decode_batch_pointer(
-                tp, tb, C.byref(used), prob_bits, int(checksum), n, _ptr_array(ts_in),
+            rc = lib().dgpu_ans_decode_batch_pointer_bounded(
+                tp, tb, C.byref(used), prob_bits, int(checksum), n, _ptr_array(ts_in), _in_bytes(ts_in),
                 _ptr_array(ts_out), _u32_array(caps), _ptr(out_status),
                 _ptr(out_decompressed_words), _stream(), C.byref(err))
         _raise_checksum(rc, compress_as_float)
@@ -268,13 +273,13 @@ def decompress_data_split_size(compress_as_float, ts_in, t_out, t_out_split_size
         used = C.c_size_t(0)
         err = C.c_int32(-1)
         if compress_as_float:
-            rc = lib().dgpu_float_decompress_split_size(
+            rc = lib().dgpu_float_decompress_split_size_bounded(
                 tp, tb, C.byref(used), _float_type(t_out), prob_bits, int(checksum), n,
-                _ptr_array(ts_in), _ptr(t_out), _u32_array(split), _ptr(out_status),
+                _ptr_array(ts_in), _in_bytes(ts_in), _ptr(t_out), _u32_array(split), _ptr(out_status),
                 _ptr(out_decompressed_words), _stream(), C.byref(err))
         else:
-            rc = lib().dgpu_ans_decode_batch_split_size(
-                tp, tb, C.byref(used), prob_bits, int(checksum), n, _ptr_array(ts_in), _ptr(t_out),
+            rc = lib().dgpu_ans_decode_batch_split_size_bounded(
+                tp, tb, C.byref(used), prob_bits, int(checksum), n, _ptr_array(ts_in), _in_bytes(ts_in), _ptr(t_out),
                 _u32_array(split), _ptr(out_status), _ptr(out_decompressed_words), _stream(),
                 C.byref(err))
         _raise_checksum(rc, compress_as_float)

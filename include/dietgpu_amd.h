@@ -192,6 +192,34 @@ int dgpu_float_decompress_split_size(
     uint8_t* outSuccess_dev, uint32_t* outSize_dev,
     void* stream, int32_t* errBatch);
 
+/* ---- decode with known input sizes (no upstream equivalent) -------------------
+ * The reference's decode API carries no compressed sizes (GpuANSCodec.h:228-304,
+ * GpuFloatCodec.h:184-258): an archive that was cut short is followed past its buffer.
+ * These variants take `inBytes` (HOST array, bytes available at in[i]); an archive whose
+ * header claims more is reported through outSuccess and not read.  The tensor API
+ * (torch.ops.dietgpu.decompress_data*, DietGpu.cpp:530-911), which knows every input
+ * tensor's size, goes through them. */
+int dgpu_ans_decode_batch_pointer_bounded(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, int probBits, int useChecksum,
+    uint32_t numInBatch, const void* const* in, const uint32_t* inBytes,
+    void* const* out, const uint32_t* outCapacity,
+    uint8_t* outSuccess_dev, uint32_t* outSize_dev, void* stream, int32_t* errBatch);
+int dgpu_ans_decode_batch_split_size_bounded(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, int probBits, int useChecksum,
+    uint32_t numInBatch, const void* const* in, const uint32_t* inBytes,
+    void* out_dev, const uint32_t* outSplitSizes,
+    uint8_t* outSuccess_dev, uint32_t* outSize_dev, void* stream, int32_t* errBatch);
+int dgpu_float_decompress_bounded(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, uint32_t floatType, int probBits, int useChecksum,
+    uint32_t numInBatch, const void* const* in, const uint32_t* inBytes,
+    void* const* out, const uint32_t* outCapacity,
+    uint8_t* outSuccess_dev, uint32_t* outSize_dev, void* stream, int32_t* errBatch);
+int dgpu_float_decompress_split_size_bounded(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, uint32_t floatType, int probBits, int useChecksum,
+    uint32_t numInBatch, const void* const* in, const uint32_t* inBytes,
+    void* out_dev, const uint32_t* outSplitSizes,
+    uint8_t* outSuccess_dev, uint32_t* outSize_dev, void* stream, int32_t* errBatch);
+
 /* floatGetCompressedInfo, GpuFloatCodec.h:264-277 / GpuFloatInfo.cu:17-45 */
 int dgpu_float_get_compressed_info(
     void* temp_dev, size_t tempBytes,

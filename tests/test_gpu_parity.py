@@ -820,6 +820,25 @@ def test_decoder_rejects_malformed_float_archives(dg):
         assert st == 0, name
 
 
+def test_decoder_rejects_truncated_archives(dg):
+    # the tensor API knows every input tensor's size (the *_bounded C entry points): an archive cut short --
+    # at any length -- is reported through the status instead of being read past its tensor
+    x = refgen.generate_symbols(6 * 4096 + 5, 20.0)
+    good = O.ans_encode(x, 10)
+    ref = torch.from_numpy(x).to(DEV)
+    for cut in (0, 8, 31, 32, 100, 544, 1300, good.size - 16, good.size - 1):
+        st, _ = _decode_status(dg, False, good[:cut] if cut else good[:1], ref)
+        assert st == 0, cut
+    w = refgen.generate_floats(O.FLOAT32, 2 * 4096 + 9)
+    fgood = O.float_compress(O.FLOAT32, w, 10)
+    fref = words_to_tensor(O.FLOAT32, w)
+    for cut in (4, 15, 16, 40, 16 + 8192 * 3, fgood.size - 2):
+        st, _ = _decode_status(dg, True, fgood[:cut], fref)
+        assert st == 0, cut
+    st, out = _decode_status(dg, True, np.concatenate([fgood, np.zeros(64, np.uint8)]), fref)  # slack after the archive is fine
+    assert st == 1 and torch.equal(out.view(torch.int32), fref.view(torch.int32))
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_decoder_fuzzed_headers_do_not_fault(dg, seed):
     # random bit flips anywhere in the header / pdf / state / block tables: the decoder either
