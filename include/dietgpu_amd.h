@@ -196,9 +196,9 @@ int dgpu_float_decompress_split_size(
  * The reference's decode API carries no compressed sizes (GpuANSCodec.h:228-304,
  * GpuFloatCodec.h:184-258): an archive that was cut short is followed past its buffer.
  * These variants take `inBytes` (HOST array, bytes available at in[i]); an archive whose
- * header claims more is reported through outSuccess and not read.  The tensor API
- * (torch.ops.dietgpu.decompress_data*, DietGpu.cpp:530-911), which knows every input
- * tensor's size, goes through them. */
+ * header claims more is reported through outSuccess and not read.  The tensor-level
+ * ops (decompress_data*, DietGpu.cpp:530-911), which know every input tensor's size,
+ * go through them. */
 int dgpu_ans_decode_batch_pointer_bounded(
     void* temp_dev, size_t tempBytes, size_t* tempUsed, int probBits, int useChecksum,
     uint32_t numInBatch, const void* const* in, const uint32_t* inBytes,
