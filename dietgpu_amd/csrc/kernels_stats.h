@@ -31,6 +31,18 @@ __device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v, uint32_t lane)
   return v;
 }
 
+// inclusive scan across the wavefront with DPP row shifts / broadcasts (6 VALU instructions, no LDS
+// crossbar round trips as with ds_bpermute shuffles)
+__device__ __forceinline__ uint32_t waveInclusiveScanDpp(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);  // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);  // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);  // row_bcast:15 -> rows 1, 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
 // ---------------------------------------------------------------------------
 // Probability normalisation (GpuANSStatistics.cuh:178-367), one 256-thread
 // workgroup per batch element.  Produces
@@ -44,9 +56,14 @@ __device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v, uint32_t lane)
 // GpuANSEncode.cuh:553-573); totalCompressedWords and the reported size are
 // completed by the encode kernel's last tile (or here for an empty input).
 //
-// The CUB block radix sort of the reference is replaced by rank-by-counting in
-// LDS (keys (q << 16) | sym are unique, so every correct sort gives the same
-// ranks); the block scan by wave64 shuffles.
+// The reference sorts (q << 16 | sym) with a CUB block radix sort and then walks the sorted order.  Neither
+// branch needs the sort here: the surplus branch adds by SYMBOL index (closed form); the deficit branch
+// subtracts 1 from "the iter smallest keys among the entries with q > 1", trip after trip, which one
+// wavefront (4 symbols per lane, in symbol order) selects with ballots: a trip that covers every q > 1 entry
+// is applied t times at once, the final partial trip finds the threshold value v* by bisection over
+// c(v) = #{1 < q <= v} and takes the first entries with q == v* in symbol order (= ascending key).  ~300
+// wave-instructions instead of the 2300 of a 256 x 256 rank-by-counting (round 1), which made batches of
+// many small elements normalisation-bound.  The block scan is wave64 DPP.
 struct NormalizeArgs {
   BatchView sizes;           // only size(b) is used
   const uint32_t* hist;      // [B][histParts][256]: per-workgroup partial histograms, summed here
@@ -82,8 +99,7 @@ struct NormalizeArgs {
 constexpr uint32_t kNormScratchWords = 3u * kNumSymbols + 4u;
 template <bool kCoherent>
 __device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const uint32_t b, uint32_t* scratch) {
-  uint32_t* sKeys = scratch;
-  uint32_t* sSorted = scratch + kNumSymbols;
+  uint32_t* sKeys = scratch;  // q per symbol
   uint32_t* sPdf = scratch + 2u * kNumSymbols;
   uint32_t* sWave = scratch + 3u * kNumSymbols;
 
@@ -144,10 +160,9 @@ __device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const u
     uint32_t q = __float2uint_rz(__fmul_rn(__uint2float_rn(W), ratio));
     q = (count > 0 && q == 0) ? 1u : q;  // :218
 
-    uint32_t s = waveReduceSum(q);
-    if (lane == 0) sWave[wave] = s;
-    const uint32_t key = (q << 16) | tid;  // :234
-    sKeys[tid] = key;
+    const uint32_t qScan = waveInclusiveScanDpp(q);
+    if (lane == 63) sWave[wave] = qScan;
+    sKeys[tid] = q;
     __syncthreads();
     const int qSum = (int)(sWave[0] + sWave[1] + sWave[2] + sWave[3]);
 
@@ -155,43 +170,70 @@ __device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const u
     if (diff >= 0) {  // uniform
       // :258-274.  Each loop trip of the reference adds 1 to every entry whose
       // SYMBOL index is < min(diff, 256): the result does not depend on the sorted
-      // order at all, so the sort (:229-241) is skipped.  Closed form of the loop:
+      // order at all.  Closed form of the loop:
       pdf = q + (uint32_t)diff / 256u + ((tid < ((uint32_t)diff % 256u)) ? 1u : 0u);
     } else {
-      // rank in descending order = number of keys greater than mine
-      uint32_t rank = 0;
-      const uint4* k4 = (const uint4*)sKeys;
-#pragma unroll 8
-      for (int i = 0; i < 64; ++i) {
-        uint4 k = k4[i];
-        rank += (k.x > key) + (k.y > key) + (k.z > key) + (k.w > key);
+      // :275-315  subtract 1 from the smallest entries that are still > 1, until the sum fits
+      if (wave == 0) {
+        const uint4 v4 = ((const uint4*)sKeys)[lane];  // symbols 4 lane .. 4 lane + 3
+        uint32_t qq[4] = {v4.x, v4.y, v4.z, v4.w};
+        // c(v) = number of entries with 1 < q <= v  (wave-uniform)
+        auto countUpTo = [&](uint32_t v) -> uint32_t {
+          uint32_t c = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) c += (uint32_t)__popcll(__ballot((qq[j] - 2u) <= (v - 2u)));
+          return c;
+        };
+        // smallest v >= 2 with c(v) >= target (1 <= target <= number of q > 1 entries)
+        auto threshold = [&](uint32_t target) -> uint32_t {
+          uint32_t lo = 2u, hi = W;
+          while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (countUpTo(mid) >= target) hi = mid;
+            else lo = mid + 1u;
+          }
+          return lo;
+        };
+        uint32_t d = (uint32_t)(-diff);
+        while (d > 0u) {
+          const uint32_t n = countUpTo(W);  // entries with q > 1 (q <= W always)
+          if (n == 0u) break;               // cannot happen: the sum would be <= 256 <= W
+          if (d >= n) {
+            // full trips: every q > 1 entry loses 1 per trip until the smallest of them reaches 1
+            const uint32_t m = threshold(1u) - 1u;
+            const uint32_t t = (d / n) < m ? (d / n) : m;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qq[j] -= (qq[j] > 1u) ? t : 0u;
+            d -= t * n;
+          } else {
+            // last, partial trip: the d smallest keys (q, then symbol) among the q > 1 entries
+            const uint32_t vs = threshold(d);
+            const uint32_t below = vs > 2u ? countUpTo(vs - 1u) : 0u;
+            const uint32_t need = d - below;  // of the entries with q == vs, the first `need` in symbol order
+            uint32_t run = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const uint64_t m64 = __ballot(qq[j] == vs);
+              run += __builtin_amdgcn_mbcnt_hi((uint32_t)(m64 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m64, 0u));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const bool eq = qq[j] == vs;
+              const bool dec = (qq[j] > 1u && qq[j] < vs) || (eq && run < need);
+              run += eq ? 1u : 0u;
+              qq[j] -= dec ? 1u : 0u;
+            }
+            d = 0u;
+          }
+        }
+        ((uint4*)sPdf)[lane] = make_uint4(qq[0], qq[1], qq[2], qq[3]);
       }
-      sSorted[rank] = key;
-      __syncthreads();
-
-      // thread r now owns the entry of rank r
-      const uint32_t rk = sSorted[tid];
-      const uint32_t rsym = rk & 0xffffu;
-      uint32_t rq = rk >> 16;
-
-      // :275-315  subtract 1 from the smallest entries that are still > 1
-      diff = -diff;
-      while (diff > 0) {
-        int numGt1 = __syncthreads_count(rq > 1);
-        int iter = diff < numGt1 ? diff : numGt1;
-        if (iter <= 0) break;
-        int start = numGt1 - iter;
-        if ((int)tid >= start && (int)tid < numGt1) rq -= 1;
-        diff -= iter;
-      }
-
-      sPdf[rsym] = rq;  // :318-334 un-sort
       __syncthreads();
       pdf = sPdf[tid];
     }
 
     // exclusive scan -> cdf  (:336-341)
-    uint32_t incl = waveInclusiveScan(pdf, lane);
+    const uint32_t incl = waveInclusiveScanDpp(pdf);
     __syncthreads();  // sWave reuse
     if (lane == 63) sWave[wave] = incl;
     __syncthreads();
