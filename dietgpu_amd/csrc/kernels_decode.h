@@ -449,10 +449,18 @@ __global__ __launch_bounds__(kTileBlocks * 32u) void k_ans_decode(DecodeArgs a) 
   uint32_t* sPdf = sCdf + kNumSymbols;
   uint32_t* sPdfSum = sPdf + kNumSymbols;
   uint32_t* sWaveBad = sPdfSum + 1;  // one flag per wave (<= 8); no static LDS in this kernel (ring alignment)
+  // small tiles (one LUT per 4 blocks): the LUT is filled by a max-scan over symbol marks instead of a
+  // binary search per slot (see below)
+  constexpr bool kScanLut = kTileBlocks == kDecBlocksPerSmallTile;
+  uint32_t* sWaveTop = sWaveBad + 8;                  // kScanLut: running maximum at the end of each wave
+  uint8_t* sMark = (uint8_t*)(sWaveTop + 8);          // kScanLut: 2^P bytes (the ring area holds 8 KiB)
   {
     {
       const bool waveBad = __ballot(!allBlocksOk) != 0ull;
       if (lane == 0u) sWaveBad[wave] = waveBad ? 1u : 0u;
+    }
+    if (kScanLut) {
+      for (uint32_t i = tid; i < (1u << P) / 4u; i += kDecThreads) ((uint32_t*)sMark)[i] = 0u;
     }
     if (wave == 0) {
       const uint2 raw = ((const uint2*)(ans + sizeof(AnsHeader)))[lane];  // pdf[4 lane .. 4 lane + 3]
@@ -477,6 +485,45 @@ __global__ __launch_bounds__(kTileBlocks * 32u) void k_ans_decode(DecodeArgs a) 
       if (a.outSize) a.outSize[b] = total;
     }
     if (!pdfOk || tile * kTileBlocks >= nb) return;  // uniform
+    if constexpr (kScanLut) {
+      // mark[cdf[s]] = s for every present symbol; sym(x) = the largest mark at or below x (cdfs ascend with
+      // the symbol; slot 0 belongs to the first present symbol, so "no mark" = 0 never surfaces)
+      for (uint32_t sidx = tid; sidx < kNumSymbols; sidx += kDecThreads) {
+        if (sPdf[sidx]) sMark[sCdf[sidx]] = (uint8_t)sidx;
+      }
+      __syncthreads();
+      constexpr uint32_t kEpt = (1u << P) / kDecThreads;  // slots per thread: 4 / 8 / 16
+      uint32_t run[kEpt];
+      {
+        const uint32_t* mw = (const uint32_t*)(sMark + tid * kEpt);
+        uint32_t m = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kEpt; ++j) {
+          const uint32_t byte = (mw[j / 4u] >> (8u * (j & 3u))) & 0xffu;
+          m = m > byte ? m : byte;
+          run[j] = m;
+        }
+      }
+      // inclusive max-scan of the per-thread maxima across the wave (DPP), then across the waves
+      uint32_t incl = run[kEpt - 1u];
+      auto dmax = [](uint32_t v, uint32_t o) { return v > o ? v : o; };
+      incl = dmax(incl, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true));
+      incl = dmax(incl, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true));
+      incl = dmax(incl, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true));
+      incl = dmax(incl, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true));
+      incl = dmax(incl, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xa, 0xf, true));
+      incl = dmax(incl, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, true));
+      uint32_t excl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x138, 0xf, 0xf, true);  // wave_shr:1
+      if (lane == 63u) sWaveTop[wave] = incl;
+      __syncthreads();
+      for (uint32_t w = 0; w < wave; ++w) excl = dmax(excl, sWaveTop[w]);
+#pragma unroll
+      for (uint32_t j = 0; j < kEpt; ++j) {
+        const uint32_t x = tid * kEpt + j;
+        const uint32_t sym = dmax(run[j], excl);
+        sLut[x] = make_uint2((sPdf[sym] & 0xfffu) | (sym << 24), (x - sCdf[sym]) & 0xfffu);
+      }
+    } else
     for (uint32_t x = tid; x < (1u << P); x += kDecThreads) {
       // last symbol s with cdf[s] <= x (zero-pdf symbols share the cdf of their
       // successor and are skipped by taking the last one)
