@@ -703,14 +703,18 @@ uint32_t encodeGridPFT(uint32_t tickets) {
 }
 template <int P, uint32_t FT>
 uint32_t encodeGridPF(uint32_t tickets, uint32_t tileBlocks) {
-  return tileBlocks == kBlocksPerSmallTile ? encodeGridPFT<P, FT, kBlocksPerSmallTile>(tickets)
-                                           : encodeGridPFT<P, FT, kBlocksPerTile>(tickets);
+  return tileBlocks == kBlocksPerTinyTile    ? encodeGridPFT<P, FT, kBlocksPerTinyTile>(tickets)
+      : tileBlocks == kBlocksPerSmallTile ? encodeGridPFT<P, FT, kBlocksPerSmallTile>(tickets)
+                                          : encodeGridPFT<P, FT, kBlocksPerTile>(tickets);
 }
 
 template <int P, uint32_t FT>
 int launchEncodePF(const EncodeArgs& a, uint32_t tileBlocks, uint32_t grid, hipStream_t stream) {
   constexpr bool kSpill = encodeSpills(FT);
-  if (tileBlocks == kBlocksPerSmallTile) {
+  if (tileBlocks == kBlocksPerTinyTile) {
+    DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT, kSpill, kBlocksPerTinyTile>), dim3(grid), dim3(kBlocksPerTinyTile * 32),
+                encLdsBytes(P, kSpill, FT, kBlocksPerTinyTile), stream, a);
+  } else if (tileBlocks == kBlocksPerSmallTile) {
     DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT, kSpill, kBlocksPerSmallTile>), dim3(grid), dim3(kBlocksPerSmallTile * 32),
                 encLdsBytes(P, kSpill, FT, kBlocksPerSmallTile), stream, a);
   } else {
@@ -759,7 +763,8 @@ int launchEncode(int P, uint32_t ft, const EncodeArgs& a, uint32_t tileBlocks, u
 
 // blocks per encoder tile for a batch whose largest element has `maxSize` symbols
 uint32_t encTileBlocksFor(uint32_t maxSize) {
-  return divUp(maxSize, kBlockSize) <= kBlocksPerSmallTile ? kBlocksPerSmallTile : kBlocksPerTile;
+  const uint32_t blocks = divUp(maxSize, kBlockSize);
+  return blocks <= kBlocksPerTinyTile ? kBlocksPerTinyTile : blocks <= kBlocksPerSmallTile ? kBlocksPerSmallTile : kBlocksPerTile;
 }
 uint32_t tilesFor(uint32_t maxSize) { return divUp(divUp(maxSize, kBlockSize), encTileBlocksFor(maxSize)); }
 
@@ -1125,7 +1130,10 @@ int floatCompressImpl(
 
 template <int P, uint32_t FT>
 int launchDecodePF(const DecodeArgs& a, uint32_t tileBlocks, dim3 grid, hipStream_t stream) {
-  if (tileBlocks == kDecBlocksPerSmallTile) {
+  if (tileBlocks == kDecBlocksPerTinyTile) {
+    DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode<P, FT, kDecBlocksPerTinyTile>), grid, dim3(kDecBlocksPerTinyTile * 32u),
+                decLdsBytes(P, FT, kDecBlocksPerTinyTile), stream, a);
+  } else if (tileBlocks == kDecBlocksPerSmallTile) {
     DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode<P, FT, kDecBlocksPerSmallTile>), grid, dim3(kDecBlocksPerSmallTile * 32u),
                 decLdsBytes(P, FT, kDecBlocksPerSmallTile), stream, a);
   } else {
@@ -1187,9 +1195,9 @@ int decodeImpl(
     }
   }
 
-  // elements of up to 8 blocks: 4-block workgroups (see kDecBlocksPerSmallTile)
+  // elements of up to 8 blocks: 4-block workgroups, of up to 2 blocks: one wavefront (see kDecBlocksPerSmallTile)
   const uint32_t maxBlocks = divUp(maxCapacity, kBlockSize);
-  const uint32_t tileBlocks = maxBlocks <= 8u ? kDecBlocksPerSmallTile : kDecBlocksPerTile;
+  const uint32_t tileBlocks = maxBlocks <= 2u ? kDecBlocksPerTinyTile : maxBlocks <= 8u ? kDecBlocksPerSmallTile : kDecBlocksPerTile;
   const uint32_t maxTiles = std::max(1u, divUp(maxBlocks, tileBlocks));
   {
     DecodeArgs d;

@@ -197,6 +197,8 @@ constexpr uint32_t kDecBlocksPerTile = 16;
 // a 16-block workgroup would leave most of its waves without a block while
 // still holding its LDS and wave slots.
 constexpr uint32_t kDecBlocksPerSmallTile = 4;
+// ... and one wavefront per element for batches of elements of at most 2 blocks
+constexpr uint32_t kDecBlocksPerTinyTile = 2;
 // Wide loads of the non-compressed bytes (16-bit float types, together with the wide stores): the 256 bytes
 // of a group fetched with one 8-byte load per lane and spread through a second LDS buffer.  Measured 3.7 us
 // SLOWER per step than the 1-byte loads (241 vs 237 us, 5 interleaved runs): off, kept as an A/B knob.
@@ -211,7 +213,10 @@ __host__ __device__ constexpr uint32_t decLdsBytes(int P, uint32_t ft, uint32_t 
   return (8u << P) + tileBlocks * kRingBytes + tileBlocks * decXposeBytes(P, ft);
 }
 
-template <int P, uint32_t FT, bool kFull, bool kWide = false>
+// kIdleUpper (full path only): the upper half of the wave has no block (the element's block count is odd, or
+// it has a single block): its lanes run the same straight-line code on don't-care data and only their
+// stores are suppressed, so the lower half keeps the fast path instead of the predicated one.
+template <int P, uint32_t FT, bool kFull, bool kWide = false, bool kIdleUpper = false>
 __device__ __forceinline__ void decodeBlock(
     uint32_t xpose,                // kWide: LDS address of this half's transposition buffer
     uint32_t state,
@@ -332,14 +337,14 @@ __device__ __forceinline__ void decodeBlock(
       if (kFull) {
         const uint32_t e0 = stepFull();
         if (kWide) sink.stageRow(xpose, (uint32_t)j, hl, e0, preCur[j]);
-        else sink.store(row, e0, preCur[j]);
+        else if (!kIdleUpper || !upper) sink.store(row, e0, preCur[j]);
       } else {
         const bool valid = row * 32u + hl < n;
         const uint32_t e0 = step(valid);
         if (valid) sink.store(row, e0, preCur[j]);
       }
     }
-    if (kFull && kWide) sink.flushGroup(xpose, (uint32_t)g, hl);
+    if (kFull && kWide && (!kIdleUpper || !upper)) sink.flushGroup(xpose, (uint32_t)g, hl);
     if (kWideNc) {
       ncCur = ncNext;
     } else {
@@ -451,9 +456,11 @@ __global__ __launch_bounds__(kTileBlocks * 32u) void k_ans_decode(DecodeArgs a) 
   uint32_t* sWaveBad = sPdfSum + 1;  // one flag per wave (<= 8); no static LDS in this kernel (ring alignment)
   // small tiles (one LUT per 4 blocks): the LUT is filled by a max-scan over symbol marks instead of a
   // binary search per slot (see below)
-  constexpr bool kScanLut = kTileBlocks == kDecBlocksPerSmallTile;
+  constexpr bool kScanLut = kTileBlocks <= kDecBlocksPerSmallTile;
   uint32_t* sWaveTop = sWaveBad + 8;                  // kScanLut: running maximum at the end of each wave
-  uint8_t* sMark = (uint8_t*)(sWaveTop + 8);          // kScanLut: 2^P bytes (the ring area holds 8 KiB)
+  // kScanLut: 2^P mark bytes in the TAIL of the LUT region -- every mark has been read (into registers) before the
+  // barrier that precedes the first LUT store
+  uint8_t* sMark = (uint8_t*)sLut + (8u << P) - (1u << P);
   {
     {
       const bool waveBad = __ballot(!allBlocksOk) != 0ull;
@@ -558,7 +565,8 @@ __global__ __launch_bounds__(kTileBlocks * 32u) void k_ans_decode(DecodeArgs a) 
   __syncthreads();  // LUT visible to every wave, scratch free (each half-wave's ring is private to its wave)
 
   RowSink<FT> sink;
-  sink.init(a.out.ptr(b), archive, floatSize, (size_t)block * kBlockSize, hl);
+  // (a half without a block points at its wave's first block: its prefetches must stay inside the archive)
+  sink.init(a.out.ptr(b), archive, floatSize, (size_t)(haveBlock ? block : (block & ~1u)) * kBlockSize, hl);
   // LDS address of the dynamic segment (0: this kernel has no static LDS); the
   // rings must be 2 KiB aligned for the and-or addressing in decodeBlock
   const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
@@ -567,12 +575,19 @@ __global__ __launch_bounds__(kTileBlocks * 32u) void k_ans_decode(DecodeArgs a) 
   const uint32_t nFirst = __shfl(n, 0, 64);
   const uint32_t nSecond = __shfl(n, 32, 64);
   const uint32_t xpose = ldsBase + kTileBlocks * kRingBytes + (8u << P) + hw * kXpose;
+  const bool wide = kXpose != 0 && (((uintptr_t)a.out.ptr(b)) & 15u) == 0;  // wide stores need a 16-byte aligned output element
   if (nFirst == kBlockSize && nSecond == kBlockSize) {
-    // wide stores need a 16-byte aligned output element (uniform per workgroup)
-    if (kXpose != 0 && (((uintptr_t)a.out.ptr(b)) & 15u) == 0) {
+    if (wide) {
       decodeBlock<P, FT, true, true>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
     } else {
       decodeBlock<P, FT, true>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
+    }
+  } else if (nFirst == kBlockSize && nSecond == 0u) {
+    // one full block in the wave (batches of single-block elements, odd block counts): fast path, idle upper half
+    if (wide) {
+      decodeBlock<P, FT, true, true, true>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
+    } else {
+      decodeBlock<P, FT, true, false, true>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
     }
   } else {
     const uint32_t maxN = nFirst > nSecond ? nFirst : nSecond;

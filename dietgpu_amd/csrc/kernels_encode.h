@@ -95,6 +95,9 @@ __host__ __device__ constexpr uint32_t encStageCap(int P, bool spill, uint32_t f
 // Blocks per tile = per workgroup: 8 (256 threads), or 4 (128 threads) for batches whose elements have
 // at most 4 blocks -- an 8-block tile would leave half of its waves without a block there.
 constexpr uint32_t kBlocksPerSmallTile = 4;
+// ... and a single wavefront (64 threads) for batches of elements of at most 2 blocks: half the LDS per workgroup,
+// twice the resident tiles
+constexpr uint32_t kBlocksPerTinyTile = 2;
 __host__ __device__ constexpr uint32_t encLdsBytes(int P, bool spill, uint32_t ft, uint32_t tileBlocks) {
   return 4096u                                       // packed symbol table
       + 128u                                         // tile bookkeeping
@@ -706,16 +709,22 @@ __global__ __launch_bounds__(kTB * 32u) __attribute__((amdgpu_waves_per_eu(6, 8)
     }
     // wave-uniform: are both halves full blocks (and the input vector-aligned)?
     const uint32_t firstBlockOfWave = tile * kTB + wave * 2u;
-    const bool waveFull = (uint64_t)(firstBlockOfWave + 2u) * kBlockSize <= (uint64_t)size &&
-        (((uintptr_t)in & 15u) == 0);
+    const bool aligned = (((uintptr_t)in & 15u) == 0);
+    const bool waveFull = (uint64_t)(firstBlockOfWave + 2u) * kBlockSize <= (uint64_t)size && aligned;
+    // ONE full block in the wave and no second one (batches of single-block elements, odd block counts): the
+    // lower half keeps the straight-line path; the upper half shadows it -- same block, same table, the same
+    // non-compressed bytes stored a second time to the same addresses -- and its results are dropped below
+    const bool waveHalf = !waveFull && aligned && firstBlockOfWave + 1u == nb &&
+        (uint64_t)(firstBlockOfWave + 1u) * kBlockSize == (uint64_t)size;
 
     ChunkSource<FT> src;
-    src.init(in, archive, size, haveBlock ? block : 0u);  // an idle half reads (and discards) word 0 of block 0
+    // (otherwise an idle half reads, and discards, word 0 of block 0)
+    src.init(in, archive, size, haveBlock ? block : (waveHalf ? firstBlockOfWave : 0u));
 
     uint32_t state;
     uint32_t words;        // words left in the LDS stage
     uint32_t spilled = 0;  // words already in the spill slot
-    if (waveFull) {
+    if (waveFull || waveHalf) {
       words = encodeRows<P, FT, true, kSpill>(src, n, kRowsPerBlock, sTable, tableLds, stageLds, dummyLds,
                                               sRing + hw * 512u, hl, upper, spillSlot, spilled, state);
     } else {
