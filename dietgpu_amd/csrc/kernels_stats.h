@@ -97,8 +97,11 @@ struct NormalizeArgs {
 // agent-scope stores) and are read with agent-scope loads.
 // `scratch`: kNormScratchWords u32 of LDS, 16-byte aligned, free for the duration of the call.
 constexpr uint32_t kNormScratchWords = 3u * kNumSymbols + 4u;
+// `direct` (nullable): this thread's count of symbol tid, when the calling workgroup has counted the whole
+// element itself (one histogram workgroup per element: no partial histograms, no arrival counter).
 template <bool kCoherent>
-__device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const uint32_t b, uint32_t* scratch) {
+__device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const uint32_t b, uint32_t* scratch,
+                                                 const uint32_t* direct = nullptr) {
   uint32_t* sKeys = scratch;  // q per symbol
   uint32_t* sPdf = scratch + 2u * kNumSymbols;
   uint32_t* sWave = scratch + 3u * kNumSymbols;
@@ -125,7 +128,9 @@ __device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const u
 
   if (total != 0) {
     uint32_t count = 0;
-    if (a.histAcc) {
+    if (direct) {
+      count = *direct;
+    } else if (a.histAcc) {
       // counts accumulated with atomics by the histogram workgroups of this element
       uint32_t* acc = a.histAcc + (size_t)b * kNumSymbols + tid;
       count = __hip_atomic_load(acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -422,6 +427,12 @@ __device__ __forceinline__ void histStore(uint32_t* __restrict__ hist, uint32_t 
   }
   __shared__ uint32_t sLast;
   __shared__ __attribute__((aligned(16))) uint32_t sScratch[kNormScratchWords];
+  if (gridDim.x == 1u) {
+    // the only histogram workgroup of its element (batches of small elements): it holds the complete counts in
+    // registers and normalises right away -- no partial histogram through memory, no arrival counter
+    normalizeElement<true>(f.norm, b, sScratch, &sum);
+    return;
+  }
   if (f.acc) {
     // few large elements: thousands of workgroups per element; their counts meet in
     // 256 atomic counters instead of thousands of partial histograms
