@@ -891,6 +891,40 @@ def test_overflow_slab_growth_inside_one_call(dg):
             assert torch.equal(outs[i], ts[i])
 
 
+def test_two_host_threads_on_one_stream(dg):
+    # ctypes releases the GIL during a call: two threads enqueue on the SAME stream with no temp memory, i.e. both
+    # carve the stream's overflow slab.  Calls serialise on the per-stream lock; every archive must be exact.
+    import threading
+
+    rng = np.random.default_rng(21)
+    jobs = []
+    for k in range(2):
+        ws = [refgen.generate_floats(O.BFLOAT16, 4096 * (5 + 3 * k) + 100 * i + k) for i in range(12)]
+        jobs.append((ws, [words_to_tensor(O.BFLOAT16, w) for w in ws], [O.float_compress(O.BFLOAT16, w, 10) for w in ws]))
+    errors = []
+    stream = torch.cuda.current_stream()
+
+    def work(k):
+        ws, ts, want = jobs[k]
+        try:
+            with torch.cuda.stream(stream):
+                for rep in range(25):
+                    comp, sizes, _ = dg.compress_data(True, ts, False, None)
+                    hs, hc = sizes.cpu().numpy(), comp.cpu().numpy()
+                    for i in range(len(ws)):
+                        if hs[i] != want[i].size or (hc[i, : hs[i]] != want[i]).any():
+                            errors.append((k, rep, i))
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:5]
+
+
 def test_stream_state_is_bounded_and_releasable(dg):
     L = dg.lib()
     L.dgpu_release_all_stream_state()
