@@ -891,6 +891,34 @@ def test_overflow_slab_growth_inside_one_call(dg):
             assert torch.equal(outs[i], ts[i])
 
 
+@pytest.mark.parametrize("prob_bits", [9, 10, 11])
+def test_whole_block_elements_in_every_tile_variant(dg, prob_bits):
+    # elements of exactly 1, 2, 3, 4, 5, 9 and 17 full blocks: waves with ONE full block take the straight-line row
+    # paths with an idle / shadow upper half; batches whose largest element has <= 2 / <= 4 / more blocks use the
+    # one-wavefront, 4-block and 8-block (16-block decode) tile variants
+    rng = np.random.default_rng(prob_bits)
+    for max_blocks in (1, 2, 3, 4, 5, 9, 17):
+        counts = [k for k in (1, 2, 3, 4, 5, 9, 17) if k <= max_blocks] + [max_blocks, 1]
+        xs = [(rng.exponential(6.0 + 9 * i, k * 4096) % 256).astype(np.uint8) for i, k in enumerate(counts)]
+        got = gpu_ans_encode(dg, xs, prob_bits, True)
+        for x, g in zip(xs, got):
+            want = O.ans_encode(x, prob_bits, use_checksum=True)
+            assert g.size == want.size and not (g != want).any(), (max_blocks, x.size)
+        outs, status, _ = gpu_ans_decode(dg, got, [x.size for x in xs], prob_bits, True)
+        assert status.all() and all((o == x).all() for o, x in zip(outs, xs))
+        for ft in (O.FLOAT16, O.BFLOAT16, O.FLOAT32):
+            ws = [refgen.generate_floats(ft, k * 4096) for k in counts]
+            ts = [words_to_tensor(ft, w) for w in ws]
+            comp, sizes, _ = dg.compress_data(True, ts, False, prob_bits=prob_bits)
+            hs, hc = sizes.cpu().numpy(), comp.cpu().numpy()
+            for i, w in enumerate(ws):
+                want = O.float_compress(ft, w, prob_bits)
+                assert hs[i] == want.size and not (hc[i, : hs[i]] != want).any(), (max_blocks, ft, w.size)
+            outs = [torch.empty_like(t) for t in ts]
+            dg.decompress_data(True, [comp[i, : hs[i]] for i in range(len(ts))], outs, False, prob_bits=prob_bits)
+            assert all((tensor_to_words(ft, o) == w).all() for o, w in zip(outs, ws))
+
+
 def test_two_host_threads_on_one_stream(dg):
     # ctypes releases the GIL during a call: two threads enqueue on the SAME stream with no temp memory, i.e. both
     # carve the stream's overflow slab.  Calls serialise on the per-stream lock; every archive must be exact.
