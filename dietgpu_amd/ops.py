@@ -53,17 +53,35 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+# ctypes arrays are cached by content: a loop that compresses the same tensors step after step (the steady
+# state the library's parameter cache is built for) then spends its host time on one tuple hash instead of
+# three array constructions per call.
+_ARRAY_CACHE = {}
+_ARRAY_CACHE_MAX = 256
+
+
+def _cached_array(ctype, values):
+    key = (ctype, values)
+    arr = _ARRAY_CACHE.get(key)
+    if arr is None:
+        if len(_ARRAY_CACHE) >= _ARRAY_CACHE_MAX:
+            _ARRAY_CACHE.clear()
+        arr = (ctype * len(values))(*values)
+        _ARRAY_CACHE[key] = arr
+    return arr
+
+
 def _ptr_array(ts):
-    return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    return _cached_array(C.c_void_p, tuple(t.data_ptr() for t in ts))
 
 
 def _u32_array(vals):
-    return (C.c_uint32 * len(vals))(*vals)
+    return _cached_array(C.c_uint32, tuple(vals))
 
 
 def _in_bytes(ts):
     """bytes each compressed input tensor holds: the decoder rejects an archive that claims more"""
-    return (C.c_uint32 * len(ts))(*[min(t.numel() * t.element_size(), _U32_MAX) for t in ts])
+    return _cached_array(C.c_uint32, tuple(min(t.numel() * t.element_size(), _U32_MAX) for t in ts))
 
 
 def _temp(temp_mem, dev):

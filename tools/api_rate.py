@@ -15,7 +15,7 @@ for name, fn_c, fn_d in (("torch.ops.dietgpu", torch.ops.dietgpu.compress_data, 
         fn_d(True, rows, outs, False, temp)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        n = 20
+        n = 200
         for _ in range(n):
             comp, sizes, _ = fn_c(True, ts, False, temp, comp, sizes)
             fn_d(True, rows, outs, False, temp)
