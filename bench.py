@@ -345,6 +345,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--elems", type=int, default=512 * 1024,
                     help="elements per tensor for the float workloads (default = BASELINE configs: 524288)")
+    ap.add_argument("--prob-bits", type=int, default=0, help="override the workload's probBits (9, 10 or 11)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--collective", action="store_true",
@@ -400,6 +401,9 @@ def main():
         D.init(backend=args.dist_backend, device=device)  # "nccl" is RCCL on ROCm
 
     data, ft, _, prob_bits, desc = make_workload(args.workload, args.batch, 1234 + rank, device, args.elems)
+    if args.prob_bits:
+        prob_bits = args.prob_bits
+        desc += f" [probBits overridden: {prob_bits}]"
     if args.collective:
         return run_collective(args, data, ft, desc, world, rank, device, D)
     codec = Codec(dg, data, ft, prob_bits)

@@ -209,14 +209,22 @@ __host__ __device__ constexpr bool decWideLoads(uint32_t ft) { return DGPU_DEC_W
 __host__ __device__ constexpr uint32_t decXposeBytes(int P, uint32_t ft) {
   return (DGPU_DEC_WIDE_STORES && P <= 10) ? (ft == kFloat32 ? 0u : ft == 0 ? 256u : 512u + (decWideLoads(ft) ? 256u : 0u)) : 0u;
 }
+// One-wavefront tiles (batches of elements of <= 2 blocks) use a COMPACT LUT entry, 4 bytes {sym:8 | x - cdf:12 |
+// pdf:12} instead of 8: residency there is set by the LDS a workgroup needs for its own LUT (measured on
+// 32768 x 4 Ki: decode 228 / 323 / 476 us with a 4 / 8 / 16 KiB LUT), and two more VALU per row to unpack do not
+// matter to a lone, latency-bound wavefront.
+__host__ __device__ constexpr bool decCompactLut(uint32_t tileBlocks) { return tileBlocks <= kDecBlocksPerTinyTile; }
+__host__ __device__ constexpr uint32_t decLutBytes(int P, uint32_t tileBlocks) {
+  return decCompactLut(tileBlocks) ? (4u << P) : (8u << P);
+}
 __host__ __device__ constexpr uint32_t decLdsBytes(int P, uint32_t ft, uint32_t tileBlocks) {
-  return (8u << P) + tileBlocks * kRingBytes + tileBlocks * decXposeBytes(P, ft);
+  return decLutBytes(P, tileBlocks) + tileBlocks * kRingBytes + tileBlocks * decXposeBytes(P, ft);
 }
 
 // kIdleUpper (full path only): the upper half of the wave has no block (the element's block count is odd, or
 // it has a single block): its lanes run the same straight-line code on don't-care data and only their
 // stores are suppressed, so the lower half keeps the fast path instead of the predicated one.
-template <int P, uint32_t FT, bool kFull, bool kWide = false, bool kIdleUpper = false>
+template <int P, uint32_t FT, bool kFull, bool kWide = false, bool kIdleUpper = false, bool kCompact = false>
 __device__ __forceinline__ void decodeBlock(
     uint32_t xpose,                // kWide: LDS address of this half's transposition buffer
     uint32_t state,
@@ -226,12 +234,20 @@ __device__ __forceinline__ void decodeBlock(
     uint32_t numWords,
     uint8_t* __restrict__ lds,     // LDS base (dynamic LDS starts at offset 0: no static __shared__ here)
     uint32_t ringBase,             // LDS address of this half's 2 KiB ring (multiple of 2048)
-    const uint2* __restrict__ lut, // LDS
+    const void* __restrict__ lutRaw, // LDS: uint2 entries, or uint32 entries (kCompact)
     const RowSink<FT>& sink,
     uint32_t hl,
     bool upper) {
   constexpr uint32_t kMask = (1u << P) - 1u;
   const uint32_t laneMaskLt = (1u << hl) - 1u;
+  // LUT entry of slot x as {pdf | sym << 24, x - cdf} (the compact form is unpacked here)
+  auto lutAt = [&](uint32_t x) -> uint2 {
+    if (kCompact) {
+      const uint32_t e = ((const uint32_t*)lutRaw)[x];
+      return make_uint2((e & 0xff000fffu), (e >> 12) & 0xfffu);
+    }
+    return ((const uint2*)lutRaw)[x];
+  };
   const uint32_t paddedBytes = roundUp(numWords, kBlockAlignWords) * 2u;
 
   // unread words of this half's block
@@ -254,7 +270,7 @@ __device__ __forceinline__ void decodeBlock(
 
   // Generic step (partial blocks): predicated, the word read under a branch.
   auto step = [&](bool valid) -> uint32_t {
-    const uint2 e = lut[state & kMask];
+    const uint2 e = lutAt(state & kMask);
     if (valid) state = __umul24(e.x, state >> P) + e.y;
     const bool read = valid && (state < kMinState);
     const uint64_t vote = __ballot(read);
@@ -274,7 +290,7 @@ __device__ __forceinline__ void decodeBlock(
   // Every lane reads a ring word (the address always falls inside the ring); only
   // lanes that need to renormalise keep it.
   auto stepFull = [&]() -> uint32_t {
-    const uint2 e = lut[state & kMask];
+    const uint2 e = lutAt(state & kMask);
     state = __umul24(e.x, state >> P) + e.y;
     const bool read = state < kMinState;
     const uint64_t vote = __ballot(read);
@@ -460,7 +476,9 @@ __global__ __launch_bounds__(kTileBlocks * 32u) void k_ans_decode(DecodeArgs a) 
   uint32_t* sWaveTop = sWaveBad + 8;                  // kScanLut: running maximum at the end of each wave
   // kScanLut: 2^P mark bytes in the TAIL of the LUT region -- every mark has been read (into registers) before the
   // barrier that precedes the first LUT store
-  uint8_t* sMark = (uint8_t*)sLut + (8u << P) - (1u << P);
+  constexpr bool kCompact = decCompactLut(kTileBlocks);
+  constexpr uint32_t kLutBytes = decLutBytes(P, kTileBlocks);
+  uint8_t* sMark = (uint8_t*)sLut + kLutBytes - (1u << P);
   {
     {
       const bool waveBad = __ballot(!allBlocksOk) != 0ull;
@@ -528,7 +546,8 @@ __global__ __launch_bounds__(kTileBlocks * 32u) void k_ans_decode(DecodeArgs a) 
       for (uint32_t j = 0; j < kEpt; ++j) {
         const uint32_t x = tid * kEpt + j;
         const uint32_t sym = dmax(run[j], excl);
-        sLut[x] = make_uint2((sPdf[sym] & 0xfffu) | (sym << 24), (x - sCdf[sym]) & 0xfffu);
+        if (kCompact) ((uint32_t*)sLut)[x] = (sPdf[sym] & 0xfffu) | (((x - sCdf[sym]) & 0xfffu) << 12) | (sym << 24);
+        else sLut[x] = make_uint2((sPdf[sym] & 0xfffu) | (sym << 24), (x - sCdf[sym]) & 0xfffu);
       }
     } else
     for (uint32_t x = tid; x < (1u << P); x += kDecThreads) {
@@ -574,24 +593,24 @@ __global__ __launch_bounds__(kTileBlocks * 32u) void k_ans_decode(DecodeArgs a) 
   // uniform per wave: both halves hold full blocks?
   const uint32_t nFirst = __shfl(n, 0, 64);
   const uint32_t nSecond = __shfl(n, 32, 64);
-  const uint32_t xpose = ldsBase + kTileBlocks * kRingBytes + (8u << P) + hw * kXpose;
+  const uint32_t xpose = ldsBase + kTileBlocks * kRingBytes + kLutBytes + hw * kXpose;
   const bool wide = kXpose != 0 && (((uintptr_t)a.out.ptr(b)) & 15u) == 0;  // wide stores need a 16-byte aligned output element
   if (nFirst == kBlockSize && nSecond == kBlockSize) {
     if (wide) {
-      decodeBlock<P, FT, true, true>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
+      decodeBlock<P, FT, true, true, false, kCompact>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
     } else {
-      decodeBlock<P, FT, true>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
+      decodeBlock<P, FT, true, false, false, kCompact>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
     }
   } else if (nFirst == kBlockSize && nSecond == 0u) {
     // one full block in the wave (batches of single-block elements, odd block counts): fast path, idle upper half
     if (wide) {
-      decodeBlock<P, FT, true, true, true>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
+      decodeBlock<P, FT, true, true, true, kCompact>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
     } else {
-      decodeBlock<P, FT, true, false, true>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
+      decodeBlock<P, FT, true, false, true, kCompact>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
     }
   } else {
     const uint32_t maxN = nFirst > nSecond ? nFirst : nSecond;
-    decodeBlock<P, FT, false>(xpose, state, n, divUp(divUp(maxN, 32u), kGroupRows), gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
+    decodeBlock<P, FT, false, false, false, kCompact>(xpose, state, n, divUp(divUp(maxN, 32u), kGroupRows), gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
   }
 }
 
