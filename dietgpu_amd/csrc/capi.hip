@@ -689,7 +689,7 @@ uint32_t encodeGridPFT(uint32_t tickets) {
   static const uint32_t perCu = [] {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &n, (k_ans_encode<P, FT, encodeSpills(FT), TB>), TB * 32, encLdsBytes(P, encodeSpills(FT), FT, TB)) != hipSuccess || n < 1) {
+            &n, (k_ans_encode<P, FT, encodeSpills(FT), TB>), encThreads(TB), encLdsBytes(P, encodeSpills(FT), FT, TB)) != hipSuccess || n < 1) {
       n = 1;
     }
     return (uint32_t)n;
@@ -703,7 +703,8 @@ uint32_t encodeGridPFT(uint32_t tickets) {
 }
 template <int P, uint32_t FT>
 uint32_t encodeGridPF(uint32_t tickets, uint32_t tileBlocks) {
-  return tileBlocks == kBlocksPerTinyTile    ? encodeGridPFT<P, FT, kBlocksPerTinyTile>(tickets)
+  return tileBlocks == kBlocksPerSingleTile  ? encodeGridPFT<P, FT, kBlocksPerSingleTile>(tickets)
+      : tileBlocks == kBlocksPerTinyTile  ? encodeGridPFT<P, FT, kBlocksPerTinyTile>(tickets)
       : tileBlocks == kBlocksPerSmallTile ? encodeGridPFT<P, FT, kBlocksPerSmallTile>(tickets)
                                           : encodeGridPFT<P, FT, kBlocksPerTile>(tickets);
 }
@@ -711,7 +712,10 @@ uint32_t encodeGridPF(uint32_t tickets, uint32_t tileBlocks) {
 template <int P, uint32_t FT>
 int launchEncodePF(const EncodeArgs& a, uint32_t tileBlocks, uint32_t grid, hipStream_t stream) {
   constexpr bool kSpill = encodeSpills(FT);
-  if (tileBlocks == kBlocksPerTinyTile) {
+  if (tileBlocks == kBlocksPerSingleTile) {
+    DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT, kSpill, kBlocksPerSingleTile>), dim3(grid), dim3(encThreads(kBlocksPerSingleTile)),
+                encLdsBytes(P, kSpill, FT, kBlocksPerSingleTile), stream, a);
+  } else if (tileBlocks == kBlocksPerTinyTile) {
     DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT, kSpill, kBlocksPerTinyTile>), dim3(grid), dim3(kBlocksPerTinyTile * 32),
                 encLdsBytes(P, kSpill, FT, kBlocksPerTinyTile), stream, a);
   } else if (tileBlocks == kBlocksPerSmallTile) {
@@ -764,7 +768,10 @@ int launchEncode(int P, uint32_t ft, const EncodeArgs& a, uint32_t tileBlocks, u
 // blocks per encoder tile for a batch whose largest element has `maxSize` symbols
 uint32_t encTileBlocksFor(uint32_t maxSize) {
   const uint32_t blocks = divUp(maxSize, kBlockSize);
-  return blocks <= kBlocksPerTinyTile ? kBlocksPerTinyTile : blocks <= kBlocksPerSmallTile ? kBlocksPerSmallTile : kBlocksPerTile;
+  return blocks <= kBlocksPerSingleTile ? kBlocksPerSingleTile
+      : blocks <= kBlocksPerTinyTile    ? kBlocksPerTinyTile
+      : blocks <= kBlocksPerSmallTile   ? kBlocksPerSmallTile
+                                        : kBlocksPerTile;
 }
 uint32_t tilesFor(uint32_t maxSize) { return divUp(divUp(maxSize, kBlockSize), encTileBlocksFor(maxSize)); }
 
@@ -1130,7 +1137,10 @@ int floatCompressImpl(
 
 template <int P, uint32_t FT>
 int launchDecodePF(const DecodeArgs& a, uint32_t tileBlocks, dim3 grid, hipStream_t stream) {
-  if (tileBlocks == kDecBlocksPerTinyTile) {
+  if (tileBlocks == kDecBlocksPerSingleTile) {
+    DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode<P, FT, kDecBlocksPerSingleTile>), grid, dim3(decThreads(kDecBlocksPerSingleTile)),
+                decLdsBytes(P, FT, kDecBlocksPerSingleTile), stream, a);
+  } else if (tileBlocks == kDecBlocksPerTinyTile) {
     DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode<P, FT, kDecBlocksPerTinyTile>), grid, dim3(kDecBlocksPerTinyTile * 32u),
                 decLdsBytes(P, FT, kDecBlocksPerTinyTile), stream, a);
   } else if (tileBlocks == kDecBlocksPerSmallTile) {
@@ -1197,7 +1207,10 @@ int decodeImpl(
 
   // elements of up to 8 blocks: 4-block workgroups, of up to 2 blocks: one wavefront (see kDecBlocksPerSmallTile)
   const uint32_t maxBlocks = divUp(maxCapacity, kBlockSize);
-  const uint32_t tileBlocks = maxBlocks <= 2u ? kDecBlocksPerTinyTile : maxBlocks <= 8u ? kDecBlocksPerSmallTile : kDecBlocksPerTile;
+  const uint32_t tileBlocks = maxBlocks <= 1u ? kDecBlocksPerSingleTile
+      : maxBlocks <= 2u                       ? kDecBlocksPerTinyTile
+      : maxBlocks <= 8u                       ? kDecBlocksPerSmallTile
+                                              : kDecBlocksPerTile;
   const uint32_t maxTiles = std::max(1u, divUp(maxBlocks, tileBlocks));
   {
     DecodeArgs d;

@@ -199,6 +199,10 @@ constexpr uint32_t kDecBlocksPerTile = 16;
 constexpr uint32_t kDecBlocksPerSmallTile = 4;
 // ... and one wavefront per element for batches of elements of at most 2 blocks
 constexpr uint32_t kDecBlocksPerTinyTile = 2;
+// ... and one ring + one store buffer for batches of single-block elements (the idle upper half of the wave
+// touches neither): 6.5 KiB per workgroup at probBits 10
+constexpr uint32_t kDecBlocksPerSingleTile = 1;
+__host__ __device__ constexpr uint32_t decThreads(uint32_t tileBlocks) { return tileBlocks * 32u < 64u ? 64u : tileBlocks * 32u; }
 // Wide loads of the non-compressed bytes (16-bit float types, together with the wide stores): the 256 bytes
 // of a group fetched with one 8-byte load per lane and spread through a second LDS buffer.  Measured 3.7 us
 // SLOWER per step than the 1-byte loads (241 vs 237 us, 5 interleaved runs): off, kept as an A/B knob.
@@ -213,7 +217,10 @@ __host__ __device__ constexpr uint32_t decXposeBytes(int P, uint32_t ft) {
 // pdf:12} instead of 8: residency there is set by the LDS a workgroup needs for its own LUT (measured on
 // 32768 x 4 Ki: decode 228 / 323 / 476 us with a 4 / 8 / 16 KiB LUT), and two more VALU per row to unpack do not
 // matter to a lone, latency-bound wavefront.
-__host__ __device__ constexpr bool decCompactLut(uint32_t tileBlocks) { return tileBlocks <= kDecBlocksPerTinyTile; }
+#ifndef DGPU_DEC_COMPACT_MAX_TILE
+#define DGPU_DEC_COMPACT_MAX_TILE 2
+#endif
+__host__ __device__ constexpr bool decCompactLut(uint32_t tileBlocks) { return tileBlocks <= DGPU_DEC_COMPACT_MAX_TILE; }
 __host__ __device__ constexpr uint32_t decLutBytes(int P, uint32_t tileBlocks) {
   return decCompactLut(tileBlocks) ? (4u << P) : (8u << P);
 }
@@ -352,8 +359,11 @@ __device__ __forceinline__ void decodeBlock(
       const uint32_t row = (uint32_t)g * kGroupRows + j;
       if (kFull) {
         const uint32_t e0 = stepFull();
-        if (kWide) sink.stageRow(xpose, (uint32_t)j, hl, e0, preCur[j]);
-        else if (!kIdleUpper || !upper) sink.store(row, e0, preCur[j]);
+        if (kWide) {
+          if (!kIdleUpper || !upper) sink.stageRow(xpose, (uint32_t)j, hl, e0, preCur[j]);
+        } else if (!kIdleUpper || !upper) {
+          sink.store(row, e0, preCur[j]);
+        }
       } else {
         const bool valid = row * 32u + hl < n;
         const uint32_t e0 = step(valid);
@@ -372,8 +382,10 @@ __device__ __forceinline__ void decodeBlock(
 
 // grid = (maxTiles, B), 32 threads per block of the tile (512 or 128), LDS = word rings + 64-bit LUT.
 template <int P, uint32_t FT, uint32_t kTileBlocks>
-__global__ __launch_bounds__(kTileBlocks * 32u) void k_ans_decode(DecodeArgs a) {
-  constexpr uint32_t kDecThreads = kTileBlocks * 32u;
+__global__ __launch_bounds__(decThreads(kTileBlocks)) void k_ans_decode(DecodeArgs a) {
+  constexpr uint32_t kDecThreads = decThreads(kTileBlocks);
+  // the LUT-build scratch (cdf, pdf: 2 KiB, read while the LUT is stored) sits in the ring area
+  static_assert(kTileBlocks * kRingBytes >= 2048u, "");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   // rings: 16 x 2 KiB at LDS offset 0 (2 KiB aligned), then the LUT, then the transposition buffers
   uint2* sLut = (uint2*)(smem + kTileBlocks * kRingBytes);
@@ -593,24 +605,25 @@ __global__ __launch_bounds__(kTileBlocks * 32u) void k_ans_decode(DecodeArgs a) 
   // uniform per wave: both halves hold full blocks?
   const uint32_t nFirst = __shfl(n, 0, 64);
   const uint32_t nSecond = __shfl(n, 32, 64);
-  const uint32_t xpose = ldsBase + kTileBlocks * kRingBytes + kLutBytes + hw * kXpose;
+  const uint32_t slot = hw < kTileBlocks ? hw : kTileBlocks - 1u;  // (single-block tiles: the idle upper half maps to slot 0 and touches nothing)
+  const uint32_t xpose = ldsBase + kTileBlocks * kRingBytes + kLutBytes + slot * kXpose;
   const bool wide = kXpose != 0 && (((uintptr_t)a.out.ptr(b)) & 15u) == 0;  // wide stores need a 16-byte aligned output element
   if (nFirst == kBlockSize && nSecond == kBlockSize) {
     if (wide) {
-      decodeBlock<P, FT, true, true, false, kCompact>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
+      decodeBlock<P, FT, true, true, false, kCompact>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + slot * kRingBytes, sLut, sink, hl, upper);
     } else {
-      decodeBlock<P, FT, true, false, false, kCompact>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
+      decodeBlock<P, FT, true, false, false, kCompact>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + slot * kRingBytes, sLut, sink, hl, upper);
     }
   } else if (nFirst == kBlockSize && nSecond == 0u) {
     // one full block in the wave (batches of single-block elements, odd block counts): fast path, idle upper half
     if (wide) {
-      decodeBlock<P, FT, true, true, true, kCompact>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
+      decodeBlock<P, FT, true, true, true, kCompact>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + slot * kRingBytes, sLut, sink, hl, upper);
     } else {
-      decodeBlock<P, FT, true, false, true, kCompact>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
+      decodeBlock<P, FT, true, false, true, kCompact>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + slot * kRingBytes, sLut, sink, hl, upper);
     }
   } else {
     const uint32_t maxN = nFirst > nSecond ? nFirst : nSecond;
-    decodeBlock<P, FT, false, false, false, kCompact>(xpose, state, n, divUp(divUp(maxN, 32u), kGroupRows), gwords, numWords, smem, ldsBase + hw * kRingBytes, sLut, sink, hl, upper);
+    decodeBlock<P, FT, false, false, false, kCompact>(xpose, state, n, divUp(divUp(maxN, 32u), kGroupRows), gwords, numWords, smem, ldsBase + slot * kRingBytes, sLut, sink, hl, upper);
   }
 }
 

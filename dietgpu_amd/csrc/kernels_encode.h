@@ -98,6 +98,11 @@ constexpr uint32_t kBlocksPerSmallTile = 4;
 // ... and a single wavefront (64 threads) for batches of elements of at most 2 blocks: half the LDS per workgroup,
 // twice the resident tiles
 constexpr uint32_t kBlocksPerTinyTile = 2;
+// ... and, for batches of SINGLE-block elements, a one-wavefront tile with one stage and one ring: the upper
+// half of the wave (which shadows the lower one, see waveHalf) shares them -- it writes the same values to the
+// same addresses -- so a workgroup needs 7 KiB instead of 10 and more of them are resident
+constexpr uint32_t kBlocksPerSingleTile = 1;
+__host__ __device__ constexpr uint32_t encThreads(uint32_t tileBlocks) { return tileBlocks * 32u < 64u ? 64u : tileBlocks * 32u; }
 __host__ __device__ constexpr uint32_t encLdsBytes(int P, bool spill, uint32_t ft, uint32_t tileBlocks) {
   return 4096u                                       // packed symbol table
       + 128u                                         // tile bookkeeping
@@ -513,8 +518,8 @@ __device__ __forceinline__ uint32_t encodeRows(
 }
 
 template <int P, uint32_t FT, bool kSpill, uint32_t kTB>
-__global__ __launch_bounds__(kTB * 32u) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_ans_encode(EncodeArgs a) {
-  constexpr uint32_t kThreads = kTB * 32u;
+__global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_ans_encode(EncodeArgs a) {
+  constexpr uint32_t kThreads = encThreads(kTB);
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr uint32_t kCap = encStageCap(P, kSpill, FT);
   // bookkeeping sits BELOW the stages so that a stage overrun (only possible
@@ -532,12 +537,13 @@ __global__ __launch_bounds__(kTB * 32u) __attribute__((amdgpu_waves_per_eu(6, 8)
   const uint32_t hl = lane & 31u;
   const uint32_t hw = wave * 2u + (upper ? 1u : 0u);
 
-  uint16_t* stage = sStage + hw * kCap;
+  const uint32_t slot = hw < kTB ? hw : kTB - 1u;  // (kTB == 1: both halves of the wave use slot 0)
+  uint16_t* stage = sStage + slot * kCap;
   const uint32_t stageLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)stage;
   const uint32_t tableLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)sTable;
   // per-lane scratch slot for non-emitting lanes (512 bytes after the rings)
   const uint32_t dummyLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(sRing + kTB * 512u) + tid * 2u;
-  uint16_t* spillSlot = kSpill ? a.spill + ((size_t)blockIdx.x * kTB + hw) * encSpillSlotWords(P) : nullptr;
+  uint16_t* spillSlot = kSpill ? a.spill + ((size_t)blockIdx.x * kTB + slot) * encSpillSlotWords(P) : nullptr;
 
 #if DGPU_SCHEDULE == 2
   // Persistent workgroups, STATIC tile map with claim words.  Workgroup w owns the
@@ -726,7 +732,7 @@ __global__ __launch_bounds__(kTB * 32u) __attribute__((amdgpu_waves_per_eu(6, 8)
     uint32_t spilled = 0;  // words already in the spill slot
     if (waveFull || waveHalf) {
       words = encodeRows<P, FT, true, kSpill>(src, n, kRowsPerBlock, sTable, tableLds, stageLds, dummyLds,
-                                              sRing + hw * 512u, hl, upper, spillSlot, spilled, state);
+                                              sRing + slot * 512u, hl, upper, spillSlot, spilled, state);
     } else {
       // rows needed by the larger of the two halves (uniform)
       uint32_t nA = 0;

@@ -6,7 +6,7 @@ rm -f /tmp/ab_*.txt
 for rep in $(seq $REPS); do
 for v in "$@"; do
   lib=""; [ "$v" != "base" ] && lib=$PWD/dietgpu_amd/lib/$v
-  DGPU_LIB=$lib python bench.py --steps ${AB_STEPS:-40} --warmup 5 --no-cpu-baseline --workload $WL > /tmp/o.json 2>/tmp/e.txt || tail -3 /tmp/e.txt
+  DGPU_LIB=$lib python bench.py --steps ${AB_STEPS:-40} --warmup 5 --no-cpu-baseline --workload $WL $AB_ARGS > /tmp/o.json 2>/tmp/e.txt || tail -3 /tmp/e.txt
   python -c "
 import json; d=json.load(open('/tmp/o.json')); print('%-18s' % '$v', d['ms_per_step'], 'enc', d['encode_ms'], 'dec', d['decode_ms'], {k[6:]: v['avg_us'] for k,v in d['kernels'].items()})
 open('/tmp/ab_$v.txt','a').write(str(d['ms_per_step'])+'\n')"
