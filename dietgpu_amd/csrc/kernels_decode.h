@@ -210,19 +210,27 @@ __host__ __device__ constexpr uint32_t decThreads(uint32_t tileBlocks) { return 
 #define DGPU_DEC_WIDE_LOADS 0
 #endif
 __host__ __device__ constexpr bool decWideLoads(uint32_t ft) { return DGPU_DEC_WIDE_LOADS && (ft == kFloat16 || ft == kBFloat16); }
-__host__ __device__ constexpr uint32_t decXposeBytes(int P, uint32_t ft) {
-  return (DGPU_DEC_WIDE_STORES && P <= 10) ? (ft == kFloat32 ? 0u : ft == 0 ? 256u : 512u + (decWideLoads(ft) ? 256u : 0u)) : 0u;
-}
-// One-wavefront tiles (batches of elements of <= 2 blocks) use a COMPACT LUT entry, 4 bytes {sym:8 | x - cdf:12 |
-// pdf:12} instead of 8: residency there is set by the LDS a workgroup needs for its own LUT (measured on
-// 32768 x 4 Ki: decode 228 / 323 / 476 us with a 4 / 8 / 16 KiB LUT), and two more VALU per row to unpack do not
-// matter to a lone, latency-bound wavefront.
-#ifndef DGPU_DEC_COMPACT_MAX_TILE
-#define DGPU_DEC_COMPACT_MAX_TILE 2
+// probBits 11: the LUT has 2048 slots; with the COMPACT 4-byte entries (below) it takes the 8 KiB the 8-byte
+// entries take at probBits 10, which leaves room for the store buffers at the same 3 workgroups per CU.
+#ifndef DGPU_DEC_COMPACT_P11
+#define DGPU_DEC_COMPACT_P11 1
 #endif
-__host__ __device__ constexpr bool decCompactLut(uint32_t tileBlocks) { return tileBlocks <= DGPU_DEC_COMPACT_MAX_TILE; }
+__host__ __device__ constexpr uint32_t decXposeBytes(int P, uint32_t ft) {
+  return (DGPU_DEC_WIDE_STORES && (P <= 10 || DGPU_DEC_COMPACT_P11)) ? (ft == kFloat32 ? 0u : ft == 0 ? 256u : 512u + (decWideLoads(ft) ? 256u : 0u)) : 0u;
+}
+// COMPACT LUT entries, 4 bytes {sym:8 | x - cdf:12 | pdf:12} instead of 8 (two more VALU per row to unpack):
+//  * tiles of <= 4 blocks (batches of small elements): residency there is set by the LDS a workgroup needs for
+//    its own LUT (measured on 32768 x 4 Ki: decode 228 / 323 / 476 us with a 4 / 8 / 16 KiB LUT; 8192 x 16 Ki:
+//    139 -> 133 us), and a lone, latency-bound wavefront does not feel the unpacking;
+//  * probBits 11 (any tile): see decXposeBytes.
+#ifndef DGPU_DEC_COMPACT_MAX_TILE
+#define DGPU_DEC_COMPACT_MAX_TILE 4
+#endif
+__host__ __device__ constexpr bool decCompactLut(int P, uint32_t tileBlocks) {
+  return tileBlocks <= DGPU_DEC_COMPACT_MAX_TILE || (DGPU_DEC_COMPACT_P11 && P >= 11);
+}
 __host__ __device__ constexpr uint32_t decLutBytes(int P, uint32_t tileBlocks) {
-  return decCompactLut(tileBlocks) ? (4u << P) : (8u << P);
+  return decCompactLut(P, tileBlocks) ? (4u << P) : (8u << P);
 }
 __host__ __device__ constexpr uint32_t decLdsBytes(int P, uint32_t ft, uint32_t tileBlocks) {
   return decLutBytes(P, tileBlocks) + tileBlocks * kRingBytes + tileBlocks * decXposeBytes(P, ft);
@@ -488,7 +496,7 @@ __global__ __launch_bounds__(decThreads(kTileBlocks)) void k_ans_decode(DecodeAr
   uint32_t* sWaveTop = sWaveBad + 8;                  // kScanLut: running maximum at the end of each wave
   // kScanLut: 2^P mark bytes in the TAIL of the LUT region -- every mark has been read (into registers) before the
   // barrier that precedes the first LUT store
-  constexpr bool kCompact = decCompactLut(kTileBlocks);
+  constexpr bool kCompact = decCompactLut(P, kTileBlocks);
   constexpr uint32_t kLutBytes = decLutBytes(P, kTileBlocks);
   uint8_t* sMark = (uint8_t*)sLut + kLutBytes - (1u << P);
   {
@@ -573,7 +581,8 @@ __global__ __launch_bounds__(decThreads(kTileBlocks)) void k_ans_decode(DecodeAr
         lo = le ? mid : lo;
         hi = le ? hi : mid;
       }
-      sLut[x] = make_uint2((sPdf[lo] & 0xfffu) | (lo << 24), (x - sCdf[lo]) & 0xfffu);
+      if (kCompact) ((uint32_t*)sLut)[x] = (sPdf[lo] & 0xfffu) | (((x - sCdf[lo]) & 0xfffu) << 12) | (lo << 24);
+      else sLut[x] = make_uint2((sPdf[lo] & 0xfffu) | (lo << 24), (x - sCdf[lo]) & 0xfffu);
     }
   }
 
