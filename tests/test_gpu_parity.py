@@ -919,6 +919,48 @@ def test_whole_block_elements_in_every_tile_variant(dg, prob_bits):
             assert all((tensor_to_words(ft, o) == w).all() for o, w in zip(outs, ws))
 
 
+@pytest.mark.parametrize("blocks", [1, 2, 4])
+@pytest.mark.parametrize("prob_bits", [9, 10, 11])
+def test_ragged_batches_of_small_elements(dg, prob_bits, blocks):
+    # batches whose LARGEST element has 1 / 2 / 4 blocks use the single-block (one stage / ring / store buffer per
+    # wavefront, the upper half shadowing or idle), one-wavefront and 4-block tile variants: empty, partial and
+    # whole blocks, compressible and incompressible (the float encoder spills the latter), with checksums
+    rng = np.random.default_rng(4400 + prob_bits + 10 * blocks)
+    ns = [0, 1, 31, 32, 33, 100, 2048, 4095, 4096, 4096, 3000, 4096, 0, 4064]
+    ns += [blocks * 4096, blocks * 4096 - 5, (blocks - 1) * 4096 + 1, blocks * 4096]
+    xs = []
+    for i, n in enumerate(ns):
+        x = rng.integers(0, 256, n, dtype=np.uint8) if i % 3 == 0 else refgen.generate_symbols(max(n, 1), 20.0 + 40 * i)[:n]
+        xs.append(np.ascontiguousarray(x, np.uint8))
+    got = gpu_ans_encode(dg, xs, prob_bits, True)
+    for x, g in zip(xs, got):
+        want = O.ans_encode(x, prob_bits, use_checksum=True)
+        assert g.size == want.size and not (g != want).any(), ("raw", x.size)
+    outs, status, osz = gpu_ans_decode(dg, got, [x.size for x in xs], prob_bits, True)
+    assert status.all() and osz.tolist() == ns and all((o == x).all() for o, x in zip(outs, xs))
+    for ft in (O.FLOAT16, O.BFLOAT16, O.FLOAT32):
+        dt = np.uint32 if ft == O.FLOAT32 else np.uint16
+        hi = 1 << (32 if ft == O.FLOAT32 else 16)
+        ws = []
+        for i, n in enumerate(ns):
+            w = rng.integers(0, hi, n, dtype=np.uint64).astype(dt) if i % 3 == 1 else refgen.generate_floats(ft, max(n, 1))[:n]
+            ws.append(np.ascontiguousarray(w, dt))
+        ts = [words_to_tensor(ft, w) for w in ws]
+        comp, sizes, _ = dg.compress_data(True, ts, True, prob_bits=prob_bits)
+        hs, hc = sizes.cpu().numpy(), comp.cpu().numpy()
+        arch = []
+        for i, w in enumerate(ws):
+            want = O.float_compress(ft, w, prob_bits, use_checksum=True)
+            assert hs[i] == want.size and not (hc[i, : hs[i]] != want).any(), (ft, w.size)
+            arch.append(comp[i, : hs[i]].clone())
+        outs = [torch.empty_like(t) for t in ts]
+        status = torch.zeros((len(ns),), dtype=torch.uint8, device=DEV)
+        osz = torch.zeros((len(ns),), dtype=torch.int32, device=DEV)
+        dg.decompress_data(True, arch, outs, True, None, status, osz, prob_bits=prob_bits)
+        assert status.cpu().numpy().all() and osz.cpu().tolist() == ns
+        assert all((tensor_to_words(ft, o) == w).all() for o, w in zip(outs, ws))
+
+
 def test_two_host_threads_on_one_stream(dg):
     # ctypes releases the GIL during a call: two threads enqueue on the SAME stream with no temp memory, i.e. both
     # carve the stream's overflow slab.  Calls serialise on the per-stream lock; every archive must be exact.
