@@ -20,6 +20,7 @@
 #include "kernels_decode.h"
 #include "kernels_encode.h"
 #include "kernels_encode_fused.h"
+#include "kernels_pairs.h"
 #include "kernels_stats.h"
 
 using namespace dgpu;
@@ -701,8 +702,25 @@ uint32_t encodeGridPFT(uint32_t tickets) {
   const uint32_t use = knob ? std::min(knob, perCu) : perCu;
   return std::max(1u, std::min(tickets, use * numComputeUnits()));
 }
+// Batches of single-block elements: two ELEMENTS per wavefront (kernels_pairs.h) instead of one with an idle half.
+#ifndef DGPU_PAIRS
+#define DGPU_PAIRS 1
+#endif
+template <int P, uint32_t FT>
+uint32_t encodePairGridPF(uint32_t elements) {
+  static const uint32_t perCu = [] {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (k_ans_encode_pair<P, FT, encodeSpills(FT)>), 64,
+                                                     encPairLdsBytes(P, encodeSpills(FT), FT)) != hipSuccess || n < 1) {
+      n = 1;
+    }
+    return (uint32_t)n;
+  }();
+  return std::max(1u, std::min((elements + 1u) / 2u, perCu * numComputeUnits()));
+}
 template <int P, uint32_t FT>
 uint32_t encodeGridPF(uint32_t tickets, uint32_t tileBlocks) {
+  if (DGPU_PAIRS && tileBlocks == kBlocksPerSingleTile) return encodePairGridPF<P, FT>(tickets);  // (one ticket per element)
   return tileBlocks == kBlocksPerSingleTile  ? encodeGridPFT<P, FT, kBlocksPerSingleTile>(tickets)
       : tileBlocks == kBlocksPerTinyTile  ? encodeGridPFT<P, FT, kBlocksPerTinyTile>(tickets)
       : tileBlocks == kBlocksPerSmallTile ? encodeGridPFT<P, FT, kBlocksPerSmallTile>(tickets)
@@ -712,7 +730,9 @@ uint32_t encodeGridPF(uint32_t tickets, uint32_t tileBlocks) {
 template <int P, uint32_t FT>
 int launchEncodePF(const EncodeArgs& a, uint32_t tileBlocks, uint32_t grid, hipStream_t stream) {
   constexpr bool kSpill = encodeSpills(FT);
-  if (tileBlocks == kBlocksPerSingleTile) {
+  if (DGPU_PAIRS && tileBlocks == kBlocksPerSingleTile) {
+    DGPU_LAUNCH("k_ans_encode_pair", stream, (k_ans_encode_pair<P, FT, kSpill>), dim3(grid), dim3(64), encPairLdsBytes(P, kSpill, FT), stream, a);
+  } else if (tileBlocks == kBlocksPerSingleTile) {
     DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT, kSpill, kBlocksPerSingleTile>), dim3(grid), dim3(encThreads(kBlocksPerSingleTile)),
                 encLdsBytes(P, kSpill, FT, kBlocksPerSingleTile), stream, a);
   } else if (tileBlocks == kBlocksPerTinyTile) {
@@ -1042,7 +1062,9 @@ int encodeCommon(
     const uint32_t grid = encodeGrid(P, floatType, tileBlocks, B * maxTiles);
     uint16_t* spill = nullptr;
     if (encodeSpills(floatType)) {
-      DGPU_ALLOC(sp, uint16_t, arena, (size_t)grid * tileBlocks * encSpillSlotWords(P));
+      // (single-block batches: two slots per workgroup, one per element of its pair)
+      const uint32_t slotsPerWg = (DGPU_PAIRS && tileBlocks == kBlocksPerSingleTile) ? 2u : tileBlocks;
+      DGPU_ALLOC(sp, uint16_t, arena, (size_t)grid * slotsPerWg * encSpillSlotWords(P));
       spill = sp;
     }
     EncodeArgs e;
@@ -1137,7 +1159,11 @@ int floatCompressImpl(
 
 template <int P, uint32_t FT>
 int launchDecodePF(const DecodeArgs& a, uint32_t tileBlocks, dim3 grid, hipStream_t stream) {
-  if (tileBlocks == kDecBlocksPerSingleTile) {
+  if (DGPU_PAIRS && tileBlocks == kDecBlocksPerSingleTile) {
+    // every capacity <= 4096 symbols: two elements per wavefront (kernels_pairs.h)
+    DGPU_LAUNCH("k_ans_decode_pair", stream, (k_ans_decode_pair<P, FT>), dim3((a.numInBatch + 1u) / 2u), dim3(64), decPairLdsBytes(P, FT),
+                stream, a);
+  } else if (tileBlocks == kDecBlocksPerSingleTile) {
     DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode<P, FT, kDecBlocksPerSingleTile>), grid, dim3(decThreads(kDecBlocksPerSingleTile)),
                 decLdsBytes(P, FT, kDecBlocksPerSingleTile), stream, a);
   } else if (tileBlocks == kDecBlocksPerTinyTile) {
@@ -1220,6 +1246,7 @@ int decodeImpl(
     d.outSuccess = useChecksum ? successForChecksum : outSuccess_dev;
     d.outSize = useChecksum ? sizesForChecksum : outSize_dev;
     d.inBytes = inBytes_dev;
+    d.numInBatch = B;
     dim3 grid(maxTiles, B);
     int rc;
     if (ft == 0) rc = launchDecodeF<0>(P, d, tileBlocks, grid, stream);

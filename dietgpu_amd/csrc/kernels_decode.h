@@ -46,6 +46,7 @@ struct DecodeArgs {
   uint32_t* outSize;       // [B] nullable
   const uint32_t* inBytes; // [B] nullable: bytes available at in.ptr(b) (the *_bounded entry points); an archive
                            // that claims to be longer is rejected instead of being read past its buffer
+  uint32_t numInBatch;     // B (k_ans_decode_pair; the general kernel takes it from the grid)
 };
 
 // ---------------------------------------------------------------------------

@@ -1,0 +1,367 @@
+// dietgpu_amd: batches of SINGLE-block elements (every element <= 4096 symbols) -- two elements per wavefront.
+//
+// The format interleaves 32 rANS states per 4 KiB block (GpuANSUtils.cuh:62-65); the coders put two blocks in a
+// wave64, lanes 0-31 and 32-63.  In a batch whose elements have one block each, the general kernels can only fill
+// one half of a wave (the other half has no block of ITS element to take) and every instruction is issued for 32
+// useful lanes: measured on 32768 x 4 Ki bf16 both coders were instruction-issue bound (PMC: encode 101 M
+// wave-instructions = 165 of its 193 us at one instruction per 4 cycles per SIMD).  These two kernels give the
+// upper half of the wave the NEXT element of the batch instead: element 2p in lanes 0-31, element 2p+1 in lanes
+// 32-63, each half with its own table / LUT, stage, ring and archive.  Everything that is wave-uniform in the
+// general kernels (element, sizes, pointers, validity) is per-half here; the row loops (encodeRows, decodeBlock)
+// are the general kernels' own.  A workgroup is one wavefront: no barriers, no look-back (an element is one tile).
+//
+// Reference semantics: ansEncodeBatch / ansDecodeBatch on elements of one block (GpuANSEncode.cuh:429-672,
+// GpuANSDecode.cuh:299-403); archives are byte-identical to the general kernels' (tests/test_gpu_parity.py::
+// test_ragged_batches_of_small_elements, test_whole_block_elements_in_every_tile_variant).
+#pragma once
+
+#include "kernels_decode.h"
+#include "kernels_encode.h"
+
+namespace dgpu {
+
+// inclusive scan over each HALF of the wavefront (rows 0-1 and rows 2-3 separately)
+__device__ __forceinline__ uint32_t halfInclusiveScanDpp(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);  // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);  // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);  // row_bcast:15 -> rows 1, 3
+  return v;
+}
+__device__ __forceinline__ uint32_t halfInclusiveMaxScanDpp(uint32_t v) {
+  auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+  v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
+  v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));
+  v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));
+  v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));
+  v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true));
+  return v;
+}
+
+// LDS fence for a single-wavefront workgroup: its LDS operations execute in order, this only stops the compiler
+// from moving accesses made through differently typed pointers across the phase boundary
+__device__ __forceinline__ void pairLdsFence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// ---------------------------------------------------------------------------
+// Encoder.  LDS: two 4 KiB tables, two stages, two 512-byte symbol rings, 128 bytes of scratch slots.
+__host__ __device__ constexpr uint32_t encPairLdsBytes(int P, bool spill, uint32_t ft) {
+  return 2u * 4096u + 2u * encStageCap(P, spill, ft) * 2u + 2u * 512u + 128u;
+}
+
+// Persistent: workgroup w encodes the pairs w, w + G, ...; a.spill holds [gridDim.x][2][encSpillSlotWords(P)].
+// The host guarantees size(b) <= 4096 for every element (encTileBlocksFor).
+template <int P, uint32_t FT, bool kSpill>
+__global__ __launch_bounds__(64) void k_ans_encode_pair(EncodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  constexpr uint32_t kCap = encStageCap(P, kSpill, FT);
+  const uint32_t lane = threadIdx.x;
+  const bool upper = lane >= 32u;
+  const uint32_t hl = lane & 31u;
+  const uint32_t half = upper ? 1u : 0u;
+
+  uint4* sTable = (uint4*)smem + half * kNumSymbols;
+  uint16_t* stage = (uint16_t*)(smem + 8192u) + half * kCap;
+  uint8_t* ring = smem + 8192u + 4u * kCap + half * 512u;
+  const uint32_t tableLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)sTable;
+  const uint32_t stageLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)stage;
+  const uint32_t dummyLds =
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(smem + 8192u + 4u * kCap + 1024u) + lane * 2u;
+  uint16_t* spillSlot = kSpill ? a.spill + ((size_t)blockIdx.x * 2u + half) * encSpillSlotWords(P) : nullptr;
+
+  const uint32_t B = a.numInBatch;
+  const uint32_t numPairs = (B + 1u) >> 1;
+#pragma unroll 1
+  for (uint32_t p = blockIdx.x; p < numPairs; p += gridDim.x) {
+    const uint32_t bLo = 2u * p, bHi = 2u * p + 1u;
+    const uint32_t sLo = a.in.size(bLo);
+    const uint32_t sHi = bHi < B ? a.in.size(bHi) : 0u;
+    if ((sLo | sHi) == 0u) continue;  // uniform: two empty elements (their headers are the normalisation's)
+    // a half without symbols (empty element, or none at all) follows its neighbour's element: it reads that
+    // element's first word, keeps nothing and writes nothing
+    const uint32_t n = upper ? sHi : sLo;
+    const bool have = n != 0u;
+    const uint32_t b = have ? (upper ? bHi : bLo) : (sLo ? bLo : bHi);
+    const uint32_t esize = have ? n : (sLo ? sLo : sHi);
+
+#pragma unroll
+    for (uint32_t i = 0; i < kNumSymbols / 32u; ++i) sTable[i * 32u + hl] = a.encTable[(size_t)b * kNumSymbols + i * 32u + hl];
+
+    const uint8_t* in = a.in.ptr(b);
+    uint8_t* archive = a.out.ptr(b);
+    uint8_t* ans = archive + ansOffsetInArchive(FT, esize);
+
+    if (FT != 0 && have) {
+      // GpuFloatHeader (GpuFloatCompress.cuh:325-337) and the zero padding of the non-comp plane(s) up to 16 bytes
+      if (hl == 0) {
+        FloatHeader h;
+        h.magicAndVersion = (kFloatMagic << 16) | kFloatVersion;
+        h.size = n;
+        h.options = FT | (a.useChecksum ? 0x10u : 0u);
+        h.checksum = (a.useChecksum && a.checksum) ? a.checksum[b] : 0u;
+        *(FloatHeader*)archive = h;
+      }
+      if (FT == kFloat32) {
+        uint16_t* nc2 = (uint16_t*)(archive + 16u);
+        uint8_t* nc1 = archive + 16u + 2u * (size_t)roundUp(n, 8u);
+        if (n + hl < roundUp(n, 8u)) nc2[n + hl] = 0;
+        if (n + hl < roundUp(n, 16u)) nc1[n + hl] = 0;
+      } else {
+        uint8_t* nc = archive + 16u;
+        if (n + hl < roundUp(n, 16u)) nc[n + hl] = 0;
+      }
+    }
+    pairLdsFence();  // tables in place
+
+    const bool fullMe = have && n == kBlockSize && (((uintptr_t)in & 15u) == 0);
+    const bool bothFull = __ballot(fullMe) == ~0ull;
+
+    ChunkSource<FT> src;
+    src.init(in, archive, esize, 0u);
+
+    uint32_t state;
+    uint32_t words;
+    uint32_t spilled = 0;
+    if (bothFull) {
+      words = encodeRows<P, FT, true, kSpill>(src, n, kRowsPerBlock, sTable, tableLds, stageLds, dummyLds, ring, hl, upper,
+                                              spillSlot, spilled, state);
+    } else {
+      const uint32_t nMax = sLo > sHi ? sLo : sHi;
+      words = encodeRows<P, FT, false, kSpill>(src, n, divUp(nMax, 32u), sTable, tableLds, stageLds, dummyLds, nullptr, hl,
+                                               upper, spillSlot, spilled, state);
+    }
+    if (!kSpill) words = words < kCap ? words : kCap;
+    pairLdsFence();  // stage complete
+
+    if (have) {
+      // final lane states (GpuANSEncode.cuh:207, :584-590)
+      ((uint32_t*)(ans + ansStatesOffset()))[hl] = state;
+      // zero the pad up to the 16-byte boundary (the spilled part is whole vectors)
+      const uint32_t padded = roundUp(words, kBlockAlignWords);
+      if (words + hl < padded) stage[words + hl] = 0;
+      const uint32_t total = spilled + words;
+      const uint32_t totalPadded = spilled + padded;
+      if (hl == 0) {
+        // complete the header (GpuANSEncode.cuh:533-566) and the block descriptors (:595-608): one block at offset 0
+        ((AnsHeader*)ans)->totalCompressedWords = totalPadded;
+        if (a.outSize) a.outSize[b] = ansOffsetInArchive(FT, n) + ansOverhead(1u) + 2u * totalPadded;
+        uint2* blockWords = (uint2*)(ans + ansBlockWordsOffset(1u));
+        blockWords[0] = make_uint2((n << 16) | total, 0u);
+        blockWords[1] = make_uint2(0u, 0u);  // alignment pad entry
+      }
+    }
+    pairLdsFence();
+    if (have) {
+      uint4* dst = (uint4*)(ans + ansOverhead(1u));
+      if (kSpill && spilled) {
+        // spilled vectors first (written by this wave; its stores must have been performed)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint4* sp = (const uint4*)spillSlot;
+        const uint32_t sv = spilled / kBlockAlignWords;
+        for (uint32_t i = hl; i < sv; i += 32u) streamStore<DGPU_NT_ENC_STORES != 0>(&dst[i], sp[i]);
+        dst += sv;
+      }
+      const uint32_t vecs = roundUp(words, kBlockAlignWords) / kBlockAlignWords;
+      const uint4* s4 = (const uint4*)stage;
+      for (uint32_t i = hl; i < vecs; i += 32u) streamStore<DGPU_NT_ENC_STORES != 0>(&dst[i], s4[i]);
+    }
+    pairLdsFence();  // the next pair overwrites tables and stages
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Decoder.  LDS: two 2 KiB rings (2 KiB aligned, at offset 0), two compact LUTs, two store buffers.
+__host__ __device__ constexpr uint32_t decPairLdsBytes(int P, uint32_t ft) {
+  return 2u * kRingBytes + 2u * (4u << P) + 2u * decXposeBytes(P, ft);
+}
+
+// grid = ceil(B / 2) workgroups of one wavefront.  The host guarantees that every output capacity is <= 4096
+// symbols, so a valid archive has at most one block.  Validation and the reporting through outSuccess / outSize are
+// k_ans_decode's, evaluated per half.
+template <int P, uint32_t FT>
+__global__ __launch_bounds__(64) void k_ans_decode_pair(DecodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  constexpr uint32_t kLutBytes = 4u << P;
+  constexpr uint32_t kXpose = decXposeBytes(P, FT);
+  const uint32_t lane = threadIdx.x;
+  const bool upper = lane >= 32u;
+  const uint32_t hl = lane & 31u;
+  const uint32_t half = upper ? 1u : 0u;
+  const uint32_t B = a.numInBatch;
+  const uint32_t b = 2u * blockIdx.x + half;
+
+  uint32_t* sLut = (uint32_t*)(smem + 2u * kRingBytes + half * kLutBytes);
+  // cdf / pdf of the 256 symbols: in this half's ring, which is not in use before the LUT is complete
+  uint32_t* sCdf = (uint32_t*)(smem + half * kRingBytes);
+  uint32_t* sPdf = sCdf + kNumSymbols;
+  // 2^P symbol marks in the tail of this half's LUT (read back into registers before the first LUT store)
+  uint8_t* sMark = (uint8_t*)sLut + kLutBytes - (1u << P);
+
+  bool live = b < B;  // this half still has an element to decode
+  const uint8_t* archive = nullptr;
+  const uint8_t* ans = nullptr;
+  uint32_t floatSize = 0, total = 0, nb = 0, totalWords = 0;
+  auto fail = [&](uint32_t reportedSize) {
+    if (hl == 0) {
+      if (a.outSuccess) a.outSuccess[b] = 0;
+      if (a.outSize) a.outSize[b] = reportedSize;
+    }
+    live = false;
+  };
+  uint64_t inBytes = ~0ull;
+  if (live) {
+    archive = a.in.ptr(b);
+    if (a.inBytes) inBytes = (uint64_t)a.inBytes[b];
+    if (inBytes < (FT ? sizeof(FloatHeader) : sizeof(AnsHeader))) fail(0u);  // not even a header
+  }
+  if (FT && live) {
+    // the float header locates the ANS archive: check it before following it
+    const FloatHeader fh = *(const FloatHeader*)archive;
+    const bool fhOk = fh.magicAndVersion == ((kFloatMagic << 16) | kFloatVersion) && (fh.options & 0xfu) == FT &&
+        fh.size <= a.out.size(b) &&
+        (uint64_t)sizeof(FloatHeader) + floatUncompDataSize(FT, fh.size) + sizeof(AnsHeader) <= inBytes;
+    if (!fhOk) fail(fh.size);
+  }
+  if (live) {
+    ans = locateAns(archive, FT, &floatSize);
+    const AnsHeader header = *(const AnsHeader*)ans;
+    nb = header.numBlocks;
+    total = header.totalUncompressedWords;
+    totalWords = header.totalCompressedWords;
+    bool success = a.out.size(b) >= total;
+    success = success && header.magicAndVersion == ((kAnsMagic << 16) | kAnsVersion) &&
+        (header.options & 0xfu) == (uint32_t)P;
+    if (FT) success = success && floatSize == total;
+    success = success && nb == divUp(total, kBlockSize);
+    success = success && (uint64_t)ansOffsetInArchive(FT, total) + ansOverhead(nb) + 2ull * totalWords <= inBytes;
+    if (!success) fail(total);
+  }
+
+  // block descriptor and pdf table (8 probabilities per lane); the sum comes out of the cdf scan
+  uint2 bw = make_uint2(0u, 0u);
+  uint32_t pdf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (live) {
+    if (nb) bw = *(const uint2*)(ans + ansBlockWordsOffset(nb));
+    const uint4 raw = ((const uint4*)(ans + sizeof(AnsHeader)))[hl];  // pdf[8 hl .. 8 hl + 7]
+    pdf[0] = raw.x & 0xffffu; pdf[1] = raw.x >> 16; pdf[2] = raw.y & 0xffffu; pdf[3] = raw.y >> 16;
+    pdf[4] = raw.z & 0xffffu; pdf[5] = raw.z >> 16; pdf[6] = raw.w & 0xffffu; pdf[7] = raw.w >> 16;
+  }
+  uint32_t mine = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) mine += pdf[j];
+  const uint32_t incl = halfInclusiveScanDpp(mine);
+  const uint32_t pdfSum = __shfl(incl, (int)(half * 32u + 31u), 64);
+  bool decodeMe = false;
+  if (live) {
+    // (nb <= 1 here: total <= capacity <= 4096)
+    bool blocksOk = true;
+    if (nb) {
+      const uint32_t w = bw.x & 0xffffu;
+      blocksOk = (bw.x >> 16) == total && (bw.y & (kBlockAlignWords - 1u)) == 0u &&
+          (uint64_t)bw.y + roundUp(w, kBlockAlignWords) <= (uint64_t)totalWords;
+    }
+    // the probabilities of a non-empty element sum to 2^P (GpuANSStatistics.cuh:256-316)
+    const bool pdfOk = nb == 0u || pdfSum == (1u << P);
+    if (hl == 0) {
+      if (a.outSuccess) a.outSuccess[b] = (blocksOk && pdfOk) ? 1 : 0;
+      if (a.outSize) a.outSize[b] = total;
+    }
+    decodeMe = nb != 0u && blocksOk && pdfOk;
+  }
+  if (__ballot(decodeMe) == 0ull) return;  // uniform
+
+  if (decodeMe) {
+    // cdf / pdf scratch and the symbol marks: mark[cdf[s]] = s for every present symbol
+    uint32_t c = incl - mine;
+    uint32_t cdf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      cdf[j] = c;
+      c += pdf[j];
+    }
+    ((uint4*)sCdf)[2u * hl] = make_uint4(cdf[0], cdf[1], cdf[2], cdf[3]);
+    ((uint4*)sCdf)[2u * hl + 1u] = make_uint4(cdf[4], cdf[5], cdf[6], cdf[7]);
+    ((uint4*)sPdf)[2u * hl] = make_uint4(pdf[0], pdf[1], pdf[2], pdf[3]);
+    ((uint4*)sPdf)[2u * hl + 1u] = make_uint4(pdf[4], pdf[5], pdf[6], pdf[7]);
+    for (uint32_t i = hl; i < (1u << P) / 4u; i += 32u) ((uint32_t*)sMark)[i] = 0u;
+    pairLdsFence();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (pdf[j]) sMark[cdf[j]] = (uint8_t)(8u * hl + (uint32_t)j);
+    }
+    pairLdsFence();
+    // sym(x) = the largest mark at or below x (cdfs ascend with the symbol; slot 0 belongs to the first present
+    // symbol, so "no mark" = 0 never surfaces); each lane owns 2^P / 32 consecutive slots
+    constexpr uint32_t kEpt = (1u << P) / 32u;
+    uint32_t run[kEpt];
+    {
+      const uint32_t* mw = (const uint32_t*)(sMark + hl * kEpt);
+      uint32_t m = 0;
+#pragma unroll
+      for (uint32_t j = 0; j < kEpt; ++j) {
+        const uint32_t byte = (mw[j / 4u] >> (8u * (j & 3u))) & 0xffu;
+        m = m > byte ? m : byte;
+        run[j] = m;
+      }
+    }
+    const uint32_t inclMax = halfInclusiveMaxScanDpp(run[kEpt - 1u]);
+    uint32_t excl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inclMax, 0x138, 0xf, 0xf, true);  // wave_shr:1
+    if (hl == 0u) excl = 0u;  // (lane 32 would see lane 31's maximum)
+    pairLdsFence();  // every mark is in registers: the LUT may overwrite them
+#pragma unroll
+    for (uint32_t j = 0; j < kEpt; ++j) {
+      const uint32_t x = hl * kEpt + j;
+      const uint32_t sym = run[j] > excl ? run[j] : excl;
+      sLut[x] = (sPdf[sym] & 0xfffu) | (((x - sCdf[sym]) & 0xfffu) << 12) | (sym << 24);
+    }
+  }
+  pairLdsFence();  // LUTs complete, scratch (= the rings) free
+
+  uint32_t state = 0, n = 0, numWords = 0;
+  const uint8_t* gwords = nullptr;
+  uint8_t* outPtr = nullptr;
+  if (decodeMe) {
+    state = ((const uint32_t*)(ans + ansStatesOffset()))[hl];
+    n = bw.x >> 16;
+    numWords = bw.x & 0xffffu;
+    gwords = ans + ansOverhead(nb) + 2u * (size_t)bw.y;
+    outPtr = a.out.ptr(b);
+  }
+  // a half with nothing to decode follows its neighbour's element (its prefetches must stay inside an archive)
+  {
+    const int other = (int)(lane ^ 32u);
+    const uint64_t oArchive = __shfl((unsigned long long)(uintptr_t)archive, other, 64);
+    const uint64_t oOut = __shfl((unsigned long long)(uintptr_t)outPtr, other, 64);
+    const uint64_t oWords = __shfl((unsigned long long)(uintptr_t)gwords, other, 64);
+    const uint32_t oFloatSize = __shfl(floatSize, other, 64);
+    if (!decodeMe) {
+      typedef __attribute__((address_space(1))) uint8_t* GlobalBytes;
+      archive = (const uint8_t*)(GlobalBytes)(uintptr_t)oArchive;
+      outPtr = (uint8_t*)(GlobalBytes)(uintptr_t)oOut;
+      gwords = (const uint8_t*)(GlobalBytes)(uintptr_t)oWords;
+      floatSize = oFloatSize;
+    }
+  }
+
+  RowSink<FT> sink;
+  sink.init(outPtr, archive, floatSize, 0, hl);
+  const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+  const uint32_t ringBase = ldsBase + half * kRingBytes;
+  const uint32_t xpose = ldsBase + 2u * kRingBytes + 2u * kLutBytes + half * kXpose;
+  const uint32_t nLo = __shfl(n, 0, 64);
+  const uint32_t nHi = __shfl(n, 32, 64);
+  // wide stores need 16-byte aligned output elements
+  const bool wide = kXpose != 0 && __ballot((((uintptr_t)outPtr) & 15u) != 0) == 0ull;
+  if (nLo == kBlockSize && nHi == kBlockSize) {
+    if (wide) {
+      decodeBlock<P, FT, true, true, false, true>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ringBase, sLut, sink, hl, upper);
+    } else {
+      decodeBlock<P, FT, true, false, false, true>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ringBase, sLut, sink, hl, upper);
+    }
+  } else {
+    const uint32_t maxN = nLo > nHi ? nLo : nHi;
+    decodeBlock<P, FT, false, false, false, true>(xpose, state, n, divUp(divUp(maxN, 32u), kGroupRows), gwords, numWords, smem, ringBase, sLut, sink, hl, upper);
+  }
+}
+
+}  // namespace dgpu

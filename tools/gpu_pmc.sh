@@ -1,11 +1,11 @@
 #!/bin/bash
 # PMC passes for our kernels on the GPU box (separate --pmc runs, no trace domains).
-# Usage: gpurun -- tools/gpu_pmc.sh <tag> [workload]
+# Usage: gpurun -- tools/gpu_pmc.sh <tag> [workload]     (PMC_ARGS="--batch 32768 --elems 4096" for other shapes)
 TAG=${1:-run}; WL=${2:-bf16}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/gpurun_out /tmp/pmc_$TAG
-BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --workload $WL"
+BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --workload $WL $PMC_ARGS"
 i=0
 for set in \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
