@@ -1,0 +1,71 @@
+"""The C ABI calls are pure stream work once warm (parameter block cached on the device, per-stream state created,
+no malloc / memcpy / synchronise per call): a compress + decompress pair can be captured into a HIP graph and
+replayed on new data.  (The reference's API cannot: StackDeviceMemory's overflow path and the per-call pointer
+uploads are host work, DietGpu.cpp:246-270.)"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("as_float", [True, False])
+def test_encode_decode_captured_in_a_hip_graph(as_float):
+    import dietgpu_amd
+    from dietgpu_amd import ops
+
+    dietgpu_amd.lib()  # fails loudly if the HIP extension is missing
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    B, n = 12, 70_000
+    g0 = torch.Generator(device="cpu").manual_seed(5)
+
+    def fresh():
+        if as_float:
+            return [torch.randn(n + 8 * i, generator=g0).to(torch.bfloat16).to(dev) for i in range(B)]
+        return [(torch.randn(n + 8 * i, generator=g0) * 20).to(torch.int8).view(torch.uint8).to(dev) for i in range(B)]
+
+    xs = fresh()
+    rows, cols = (ops.max_float_compressed_output_size(xs) if as_float else ops.max_any_compressed_output_size(xs))
+    comp = torch.empty((rows, cols), dtype=torch.uint8, device=dev)
+    sizes = torch.zeros((rows,), dtype=torch.int32, device=dev)
+    outs = [torch.empty_like(x) for x in xs]
+    status = torch.zeros((B,), dtype=torch.uint8, device=dev)
+    osz = torch.zeros((B,), dtype=torch.int32, device=dev)
+    temp = torch.empty((128 << 20,), dtype=torch.uint8, device=dev)
+
+    def roundtrip():
+        ops.compress_data(as_float, xs, False, temp, comp, sizes)
+        ops.decompress_data(as_float, [comp[i] for i in range(B)], outs, False, temp, status, osz)
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):  # warm: uploads the parameter blocks, creates this stream's library state
+            roundtrip()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        roundtrip()
+    torch.cuda.synchronize()
+
+    for trial in range(3):
+        new = fresh()
+        for x, y in zip(xs, new):
+            x.copy_(y)
+        for o in outs:
+            o.zero_()
+        status.zero_()
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert bool(status.all())
+        assert osz.cpu().tolist() == [x.numel() for x in xs]
+        for x, o in zip(xs, outs):
+            assert torch.equal(x.view(torch.uint8), o.view(torch.uint8)), trial
+        # the archives of the replay are what a plain call produces
+        ref_comp, ref_sizes, _ = ops.compress_data(as_float, xs, False, temp)
+        torch.cuda.synchronize()
+        assert torch.equal(ref_sizes, sizes)
+        for i in range(B):
+            k = int(sizes[i])
+            assert torch.equal(ref_comp[i, :k], comp[i, :k])
