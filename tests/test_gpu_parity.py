@@ -928,6 +928,7 @@ def test_ragged_batches_of_small_elements(dg, prob_bits, blocks):
     rng = np.random.default_rng(4400 + prob_bits + 10 * blocks)
     ns = [0, 1, 31, 32, 33, 100, 2048, 4095, 4096, 4096, 3000, 4096, 0, 4064]
     ns += [blocks * 4096, blocks * 4096 - 5, (blocks - 1) * 4096 + 1, blocks * 4096]
+    ns += [4096] * 6  # pairs of whole blocks with an incompressible member (the straight-line path, spilling)
     xs = []
     for i, n in enumerate(ns):
         x = rng.integers(0, 256, n, dtype=np.uint8) if i % 3 == 0 else refgen.generate_symbols(max(n, 1), 20.0 + 40 * i)[:n]
