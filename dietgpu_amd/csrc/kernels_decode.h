@@ -69,6 +69,18 @@ typedef __attribute__((address_space(3))) uint16_t LdsU16w;
 typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4w LdsU4w;
 
+// {e0.b3 (symbol), r.b0 (non-compressed byte), e0.b1, e0.b0} in one v_perm_b32.  Only byte 0 of r is used, so the
+// byte loaded a group earlier needs no zero-extension when it is consumed (as (r << 16) | e0 the compiler
+// re-masked it with a v_and per row: the value crosses the loop edge as an i8, and the zero-extension is sunk
+// away from the load).
+#ifndef DGPU_DEC_PERM_JOIN
+#define DGPU_DEC_PERM_JOIN 1
+#endif
+__device__ __forceinline__ uint32_t joinBytes(uint32_t e0, uint32_t r) {
+  if (DGPU_DEC_PERM_JOIN) return __builtin_amdgcn_perm(e0, r, 0x07000504u);
+  return (r << 16) | e0;
+}
+
 template <uint32_t FT>
 struct RowSink;
 
@@ -78,20 +90,25 @@ struct RowSink<0> {  // raw bytes (BatchWriter, BatchProvider.cuh:16-37)
   __device__ __forceinline__ void init(uint8_t* outBase, const uint8_t*, uint32_t, size_t first, uint32_t hl) {
     out = outBase + first + hl;
   }
+  typedef uint32_t Pre;
   __device__ __forceinline__ uint32_t prefetch(uint32_t) const { return 0; }
   __device__ __forceinline__ void store(uint32_t row, uint32_t e0, uint32_t) const {
     out[row * 32u] = (uint8_t)(e0 >> 24);  // 32-byte row pieces: left to the L2 to merge
   }
-  // wide-store variant: the 8 rows of a group meet in a 256-byte LDS buffer, every lane stores 8 bytes
-  static constexpr uint32_t kXposeBytes = 256;
+  // wide-store variant: every row leaves the TOP half of LUT word 0 ({sym, 0}) in a 512-byte LDS buffer as it is
+  // (ds_write_b16_d16_hi: no VALU in the row); a lane then holds 8 consecutive symbols as four {sym, 0, sym, 0}
+  // dwords, packs them with two v_perm_b32 and stores 8 bytes
+  static constexpr uint32_t kXposeBytes = 512;
   __device__ __forceinline__ uint2 prefetchGroup(uint32_t, uint32_t) const { return make_uint2(0, 0); }
-  __device__ __forceinline__ void stageRow(uint32_t xpose, uint32_t j, uint32_t hl, uint32_t e0, uint32_t) const {
-    *(__attribute__((address_space(3))) uint8_t*)(uintptr_t)(xpose + j * 32u + hl) = (uint8_t)(e0 >> 24);
+  __device__ __forceinline__ void stageRow(uint32_t xpose, uint32_t j, uint32_t hl, uint32_t e0) const {
+    *(LdsU16w*)(uintptr_t)(xpose + (j * 32u + hl) * 2u) = (uint16_t)(e0 >> 16);
   }
-  __device__ __forceinline__ void flushGroup(uint32_t xpose, uint32_t g, uint32_t hl) const {
+  __device__ __forceinline__ void flushGroup(uint32_t xpose, uint32_t g, uint32_t hl, uint2) const {
     typedef uint32_t u32x2l __attribute__((ext_vector_type(2)));
-    const u32x2l v = *(const __attribute__((address_space(3))) u32x2l*)(uintptr_t)(xpose + hl * 8u);
-    *(u32x2l*)(out - hl + g * 256u + hl * 8u) = v;
+    const u32x4w v = *(const LdsU4w*)(uintptr_t)(xpose + hl * 16u);
+    const uint32_t o0 = __builtin_amdgcn_perm(v.y, v.x, 0x07050301u);  // {x.b1, x.b3, y.b1, y.b3}
+    const uint32_t o1 = __builtin_amdgcn_perm(v.w, v.z, 0x07050301u);
+    *(u32x2l*)(out - hl + g * 256u + hl * 8u) = u32x2l{o0, o1};
   }
 };
 
@@ -103,22 +120,29 @@ struct RowSink<kFloat16> {  // word = comp << 8 | nonComp
     out = (uint16_t*)outBase + first + hl;
     nc = archive + 16u + first + hl;
   }
+  typedef uint32_t Pre;
   __device__ __forceinline__ uint32_t prefetch(uint32_t row) const { return nc[row * 32u]; }
   __device__ __forceinline__ void store(uint32_t row, uint32_t e0, uint32_t r) const {
-    const uint32_t v = (r << 16) | e0;  // [sym][nc][0000 pdf]
+    const uint32_t v = joinBytes(e0, r);  // [sym][nc][0000 pdf]
     streamStore<DGPU_NT_DEC_STORES != 0>(&out[row * 32u], (uint16_t)(v >> 16));
   }
+  // wide variant (see decodeBlock): rows stage {sym, 0}; a lane joins its 8 consecutive words with the 8
+  // non-compressed bytes it loaded with ONE 8-byte load: one v_perm_b32 per pair of words
   static constexpr uint32_t kXposeBytes = 512;
   __device__ __forceinline__ uint2 prefetchGroup(uint32_t g, uint32_t hl) const { return *(const uint2*)(nc - hl + g * 256u + hl * 8u); }
-  __device__ __forceinline__ void stageRow(uint32_t xpose, uint32_t j, uint32_t hl, uint32_t e0, uint32_t r) const {
-    const uint32_t v = (r << 16) | e0;
-    *(LdsU16w*)(uintptr_t)(xpose + (j * 32u + hl) * 2u) = (uint16_t)(v >> 16);
+  __device__ __forceinline__ void stageRow(uint32_t xpose, uint32_t j, uint32_t hl, uint32_t e0) const {
+    *(LdsU16w*)(uintptr_t)(xpose + (j * 32u + hl) * 2u) = (uint16_t)(e0 >> 16);
   }
-  __device__ __forceinline__ void flushGroup(uint32_t xpose, uint32_t g, uint32_t hl) const {
+  __device__ __forceinline__ void flushGroup(uint32_t xpose, uint32_t g, uint32_t hl, uint2 ncb) const {
     const u32x4w v = *(const LdsU4w*)(uintptr_t)(xpose + hl * 16u);
+    u32x4w o;
+    o.x = __builtin_amdgcn_perm(v.x, ncb.x, 0x07010500u);  // {nc0, sym0, nc1, sym1}
+    o.y = __builtin_amdgcn_perm(v.y, ncb.x, 0x07030502u);
+    o.z = __builtin_amdgcn_perm(v.z, ncb.y, 0x07010500u);
+    o.w = __builtin_amdgcn_perm(v.w, ncb.y, 0x07030502u);
     u32x4w* dst = (u32x4w*)(out - hl + g * 256u + hl * 8u);
-    if (DGPU_NT_DEC_STORES) __builtin_nontemporal_store(v, dst);
-    else *dst = v;
+    if (DGPU_NT_DEC_STORES) __builtin_nontemporal_store(o, dst);
+    else *dst = o;
   }
 };
 
@@ -130,24 +154,38 @@ struct RowSink<kBFloat16> {  // word = (comp << 8 | nonComp) >> 1 | (nonComp & 1
     out = (uint16_t*)outBase + first + hl;
     nc = archive + 16u + first + hl;
   }
+  typedef uint32_t Pre;
   __device__ __forceinline__ uint32_t prefetch(uint32_t row) const { return nc[row * 32u]; }
   __device__ __forceinline__ void store(uint32_t row, uint32_t e0, uint32_t r) const {
-    const uint32_t lo = (r << 16) | e0;                                   // [sym][nc][0000 pdf]
-    const uint32_t v = __builtin_amdgcn_alignbit(r, lo, 1);               // (lo >> 1) | (r << 31)
+    const uint32_t lo = joinBytes(e0, r);                                 // [sym][nc][0000 pdf]
+    const uint32_t v = __builtin_amdgcn_alignbit(r, lo, 1);     // (lo >> 1) | (r << 31)
     streamStore<DGPU_NT_DEC_STORES != 0>(&out[row * 32u], (uint16_t)(v >> 16));                    // [sign][exp][mant7]
   }
+  // wide variant: as fp16, then every 16-bit half {exp, nc} rotated right by one (sign to the top):
+  // (h >> 1) + h * 2^15 on packed halves (v_pk_lshrrev_b16 + v_pk_mad_u16)
   static constexpr uint32_t kXposeBytes = 512;
   __device__ __forceinline__ uint2 prefetchGroup(uint32_t g, uint32_t hl) const { return *(const uint2*)(nc - hl + g * 256u + hl * 8u); }
-  __device__ __forceinline__ void stageRow(uint32_t xpose, uint32_t j, uint32_t hl, uint32_t e0, uint32_t r) const {
-    const uint32_t lo = (r << 16) | e0;
-    const uint32_t v = __builtin_amdgcn_alignbit(r, lo, 1);
-    *(LdsU16w*)(uintptr_t)(xpose + (j * 32u + hl) * 2u) = (uint16_t)(v >> 16);
+  __device__ __forceinline__ void stageRow(uint32_t xpose, uint32_t j, uint32_t hl, uint32_t e0) const {
+    *(LdsU16w*)(uintptr_t)(xpose + (j * 32u + hl) * 2u) = (uint16_t)(e0 >> 16);
   }
-  __device__ __forceinline__ void flushGroup(uint32_t xpose, uint32_t g, uint32_t hl) const {
+  static __device__ __forceinline__ uint32_t rotrHalves(uint32_t x) {
+    typedef uint16_t u16x2w __attribute__((ext_vector_type(2)));
+    const u16x2w h = __builtin_bit_cast(u16x2w, x);
+    const uint32_t shifted = __builtin_bit_cast(uint32_t, (u16x2w)(h >> 1));
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(0x80008000u), "v"(shifted));
+    return r;
+  }
+  __device__ __forceinline__ void flushGroup(uint32_t xpose, uint32_t g, uint32_t hl, uint2 ncb) const {
     const u32x4w v = *(const LdsU4w*)(uintptr_t)(xpose + hl * 16u);
+    u32x4w o;
+    o.x = rotrHalves(__builtin_amdgcn_perm(v.x, ncb.x, 0x07010500u));
+    o.y = rotrHalves(__builtin_amdgcn_perm(v.y, ncb.x, 0x07030502u));
+    o.z = rotrHalves(__builtin_amdgcn_perm(v.z, ncb.y, 0x07010500u));
+    o.w = rotrHalves(__builtin_amdgcn_perm(v.w, ncb.y, 0x07030502u));
     u32x4w* dst = (u32x4w*)(out - hl + g * 256u + hl * 8u);
-    if (DGPU_NT_DEC_STORES) __builtin_nontemporal_store(v, dst);
-    else *dst = v;
+    if (DGPU_NT_DEC_STORES) __builtin_nontemporal_store(o, dst);
+    else *dst = o;
   }
 };
 
@@ -161,6 +199,7 @@ struct RowSink<kFloat32> {  // rotr32(comp << 24 | nonComp24, 1)
     nc2 = (const uint16_t*)(archive + 16u) + first + hl;
     nc1 = archive + 16u + 2u * (size_t)roundUp(floatSize, 8u) + first + hl;
   }
+  typedef uint32_t Pre;
   __device__ __forceinline__ uint32_t prefetch(uint32_t row) const {
     return ((uint32_t)nc1[row * 32u] << 16) | nc2[row * 32u];
   }
@@ -170,8 +209,8 @@ struct RowSink<kFloat32> {  // rotr32(comp << 24 | nonComp24, 1)
   }
   static constexpr uint32_t kXposeBytes = 0;  // 128-byte row pieces already: no transposition
   __device__ __forceinline__ uint2 prefetchGroup(uint32_t, uint32_t) const { return make_uint2(0, 0); }
-  __device__ __forceinline__ void stageRow(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t) const {}
-  __device__ __forceinline__ void flushGroup(uint32_t, uint32_t, uint32_t) const {}
+  __device__ __forceinline__ void stageRow(uint32_t, uint32_t, uint32_t, uint32_t) const {}
+  __device__ __forceinline__ void flushGroup(uint32_t, uint32_t, uint32_t, uint2) const {}
 };
 
 // ---------------------------------------------------------------------------
@@ -204,20 +243,23 @@ constexpr uint32_t kDecBlocksPerTinyTile = 2;
 // touches neither): 6.5 KiB per workgroup at probBits 10
 constexpr uint32_t kDecBlocksPerSingleTile = 1;
 __host__ __device__ constexpr uint32_t decThreads(uint32_t tileBlocks) { return tileBlocks * 32u < 64u ? 64u : tileBlocks * 32u; }
-// Wide loads of the non-compressed bytes (16-bit float types, together with the wide stores): the 256 bytes
-// of a group fetched with one 8-byte load per lane and spread through a second LDS buffer.  Measured 3.7 us
-// SLOWER per step than the 1-byte loads (241 vs 237 us, 5 interleaved runs): off, kept as an A/B knob.
-#ifndef DGPU_DEC_WIDE_LOADS
-#define DGPU_DEC_WIDE_LOADS 0
-#endif
-__host__ __device__ constexpr bool decWideLoads(uint32_t ft) { return DGPU_DEC_WIDE_LOADS && (ft == kFloat16 || ft == kBFloat16); }
 // probBits 11: the LUT has 2048 slots; with the COMPACT 4-byte entries (below) it takes the 8 KiB the 8-byte
 // entries take at probBits 10, which leaves room for the store buffers at the same 3 workgroups per CU.
 #ifndef DGPU_DEC_COMPACT_P11
 #define DGPU_DEC_COMPACT_P11 1
 #endif
-__host__ __device__ constexpr uint32_t decXposeBytes(int P, uint32_t ft) {
-  return (DGPU_DEC_WIDE_STORES && (P <= 10 || DGPU_DEC_COMPACT_P11)) ? (ft == kFloat32 ? 0u : ft == 0 ? 256u : 512u + (decWideLoads(ft) ? 256u : 0u)) : 0u;
+// Raw bytes in 16-block tiles keep the narrow stores (DGPU_DEC_RAW_WIDE16 = 0): their row loop is bound by the
+// latency of its dependent chain (two LDS round trips per row), not by the stores or by instruction issue --
+// four extra s_nop per row cost 0.6 %, four extra VALU moves 2.5 % (tools/issue_model.sh) -- so a fourth
+// workgroup per CU (40 KiB instead of 48: 8 waves per SIMD) is worth more than the 8-byte stores:
+// 256 x 1 MiB Zipf bytes decode 152.5 -> 145 us.  (16-bit floats are HBM-bound with the wide stores, and their
+// narrow 2-byte non-temporal stores inflate the write traffic by 1.35, section 4.2 of DESIGN.md.)
+#ifndef DGPU_DEC_RAW_WIDE16
+#define DGPU_DEC_RAW_WIDE16 0
+#endif
+__host__ __device__ constexpr uint32_t decXposeBytes(int P, uint32_t ft, uint32_t tileBlocks) {
+  if (ft == 0 && tileBlocks >= 16u && !DGPU_DEC_RAW_WIDE16) return 0u;
+  return (DGPU_DEC_WIDE_STORES && (P <= 10 || DGPU_DEC_COMPACT_P11)) ? (ft == kFloat32 ? 0u : 512u) : 0u;
 }
 // COMPACT LUT entries, 4 bytes {sym:8 | x - cdf:12 | pdf:12} instead of 8 (two more VALU per row to unpack):
 //  * tiles of <= 4 blocks (batches of small elements): residency there is set by the LDS a workgroup needs for
@@ -234,13 +276,29 @@ __host__ __device__ constexpr uint32_t decLutBytes(int P, uint32_t tileBlocks) {
   return decCompactLut(P, tileBlocks) ? (4u << P) : (8u << P);
 }
 __host__ __device__ constexpr uint32_t decLdsBytes(int P, uint32_t ft, uint32_t tileBlocks) {
-  return decLutBytes(P, tileBlocks) + tileBlocks * kRingBytes + tileBlocks * decXposeBytes(P, ft);
+  return decLutBytes(P, tileBlocks) + tileBlocks * kRingBytes + tileBlocks * decXposeBytes(P, ft, tileBlocks);
 }
 
 // kIdleUpper (full path only): the upper half of the wave has no block (the element's block count is odd, or
 // it has a single block): its lanes run the same straight-line code on don't-care data and only their
 // stores are suppressed, so the lower half keeps the fast path instead of the predicated one.
-template <int P, uint32_t FT, bool kFull, bool kWide = false, bool kIdleUpper = false, bool kCompact = false>
+//
+// Position tracking (kFull, DGPU_DEC_SCALAR_POS): the unread-word counts of the two halves are wave-uniform, so
+// they live in two SGPRs (s_bcnt1 of the ballot halves); a reading lane's word index comes from
+// v_mbcnt_lo + v_mbcnt_hi over the 64-bit ballot (lower half: its rank; upper half: rank + readers of the lower
+// half) plus one v_mad_i32_i24 that moves the upper half onto its own position: 4-5 VALU per row where the
+// per-lane bookkeeping (half select by a 64-bit shift, two popcounts, subtract, mask, shift-add) took 7.
+//
+// kNoRing (kFull): both blocks of the wave have <= 1024 compressed words (every exponent block of N(0,1)
+// bf16 has ~650), so the whole block is staged once and the ring maintenance, the wrap mask and the base OR
+// disappear from the row loop (the base is folded into the scalar positions).
+#ifndef DGPU_DEC_SCALAR_POS
+#define DGPU_DEC_SCALAR_POS 1
+#endif
+#ifndef DGPU_DEC_NORING
+#define DGPU_DEC_NORING 1
+#endif
+template <int P, uint32_t FT, bool kFull, bool kWide = false, bool kIdleUpper = false, bool kCompact = false, bool kNoRing = false>
 __device__ __forceinline__ void decodeBlock(
     uint32_t xpose,                // kWide: LDS address of this half's transposition buffer
     uint32_t state,
@@ -269,9 +327,25 @@ __device__ __forceinline__ void decodeBlock(
   // unread words of this half's block
   uint32_t posw = numWords;
 
+  static_assert(!kNoRing || kFull, "whole-block staging is a full-block path");
   // initial fill: every chunk that intersects [numWords - 512, numWords)
   int lowChunk = numWords ? (int)((numWords - 1u) / kRingChunkWords) + 1 : 0;  // lowest chunk requested so far (+1 = none)
-  {
+  if (kNoRing) {
+    // the whole block (<= 1024 words = the 2 KiB ring region), word i at ringBase + 2 i
+    uint4 v[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {
+      const uint32_t off = (k * 32u + hl) * 16u;
+      v[k] = make_uint4(0, 0, 0, 0);
+      if (off < paddedBytes) v[k] = *(const uint4*)(gwords + off);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {
+      const uint32_t off = (k * 32u + hl) * 16u;
+      if (off < paddedBytes) *(LdsU4*)(uintptr_t)(ringBase + off) = u32x4{v[k].x, v[k].y, v[k].z, v[k].w};
+    }
+    lowChunk = 0;
+  } else {
     const int stop = numWords > 512u ? (int)((numWords - 512u) / kRingChunkWords) : 0;
     while (lowChunk > stop) {
       --lowChunk;
@@ -305,11 +379,52 @@ __device__ __forceinline__ void decodeBlock(
   // Full-block step: straight-line code, no exec-mask change and no branch.
   // Every lane reads a ring word (the address always falls inside the ring); only
   // lanes that need to renormalise keep it.
+  // wave-uniform positions (SGPRs): unread words of the lower / upper half's block; kNoRing: plus the LDS word
+  // address of the block's staging area, so that (position + rank) << 1 IS the LDS address
+  constexpr bool kScalarPos = kFull && (DGPU_DEC_SCALAR_POS || kNoRing);
+  uint32_t sLo = 0, sHi = 0;
+  if (kScalarPos) {
+    sLo = __builtin_amdgcn_readlane(numWords, 0);
+    sHi = __builtin_amdgcn_readlane(numWords, 32);
+    if (kNoRing) {
+      sLo += __builtin_amdgcn_readlane(ringBase, 0) >> 1;
+      sHi += __builtin_amdgcn_readlane(ringBase, 32) >> 1;
+    }
+  }
+  // an idle upper half follows the lower half's addresses (in bounds; its words are never used)
+  int upperSel = (upper && !kIdleUpper) ? 1 : 0;
+#ifdef DGPU_DEC_PAD_VALU
+  uint32_t padReg = hl;
+#endif
+  asm volatile("" : "+v"(upperSel));  // a VGPR operand of the multiply-add, not a select to be folded into it
   auto stepFull = [&]() -> uint32_t {
     const uint2 e = lutAt(state & kMask);
     state = __umul24(e.x, state >> P) + e.y;
     const bool read = state < kMinState;
     const uint64_t vote = __ballot(read);
+#ifdef DGPU_DEC_PAD_SNOP  // issue-model experiment (tools/issue_model.sh): N extra scalar no-ops per row
+#pragma unroll
+    for (int i = 0; i < DGPU_DEC_PAD_SNOP; ++i) asm volatile("s_nop 0");
+#endif
+#ifdef DGPU_DEC_PAD_VALU  // ... or N extra independent VALU moves per row
+#pragma unroll
+    for (int i = 0; i < DGPU_DEC_PAD_VALU; ++i) asm volatile("v_mov_b32 %0, %0" : "+v"(padReg));
+#endif
+    if (kScalarPos) {
+      const uint32_t vLo = (uint32_t)vote, vHi = (uint32_t)(vote >> 32);
+      const uint32_t sLoOld = sLo;
+      sLo -= (uint32_t)__popc(vLo);
+      sHi -= (uint32_t)__popc(vHi);
+      // readers below me in the wave: lower half = my rank, upper half = rank + readers of the lower half
+      uint32_t t = __builtin_amdgcn_mbcnt_hi(vHi, __builtin_amdgcn_mbcnt_lo(vLo, 0u));
+      // lower: sLo + rank; upper: sHi + rank = sLo + (rank + readersLo) + (sHi - sLoOld)
+      t = (uint32_t)(__mul24(upperSel, (int)(sHi - sLoOld)) + (int)t);
+      asm volatile("" : "+v"(t));  // keep the scalar position in the add-shift below (one SGPR operand per VALU op)
+      const uint32_t addr = kNoRing ? ((t + sLo) << 1) : ((((t + sLo) << 1) & (kRingBytes - 1u)) | ringBase);
+      const uint32_t w = *(const LdsU16*)(uintptr_t)addr;
+      state = read ? ((state << kEncodedBits) | w) : state;
+      return e.x;
+    }
     const uint32_t vh = upper ? (uint32_t)(vote >> 32) : (uint32_t)vote;
     posw -= __popc(vh);
     const uint32_t idx = posw + __popc(vh & laneMaskLt);
@@ -318,50 +433,49 @@ __device__ __forceinline__ void decodeBlock(
     return e.x;
   };
 
-  // Non-compressed bytes are fetched one whole group ahead.  The loads are
-  // unconditional (row index clamped) so that the compiler can use counted
-  // vmcnt waits instead of draining the memory queue every group.
-  uint32_t preCur[kGroupRows], preNext[kGroupRows];
+  // Non-compressed bytes are fetched one whole group ahead.
+  //  * wide path: ONE 8-byte load per lane and group -- the 8 consecutive bytes that belong to the 8 consecutive
+  //    words the lane stores; they meet the decoded symbols only at the flush (RowSink::flushGroup), so a row
+  //    costs no VALU for the join and no byte load;
+  //  * otherwise one byte load per row, unconditional (row index clamped) so that the compiler can use counted
+  //    vmcnt waits instead of draining the memory queue every group.
+  typedef typename RowSink<FT>::Pre Pre;
+  constexpr bool kJoinAtFlush = kFull && kWide;
+  Pre preCur[kGroupRows], preNext[kGroupRows];
   const int lastGroup = (int)groups - 1;
-  constexpr bool kWideNc = kFull && kWide && decWideLoads(FT);
-  const uint32_t xposeNc = xpose + 512u;  // second buffer (kWideNc)
   uint2 ncCur = make_uint2(0, 0), ncNext = make_uint2(0, 0);
-  if (kWideNc) ncCur = sink.prefetchGroup((uint32_t)lastGroup, hl);
+  if (kJoinAtFlush) ncCur = sink.prefetchGroup((uint32_t)lastGroup, hl);
 #pragma unroll
   for (int j = 0; j < (int)kGroupRows; ++j) {
     const uint32_t row = (uint32_t)lastGroup * kGroupRows + j;
-    preCur[j] = kWideNc ? 0u : ((kFull || row * 32u + hl < n) ? sink.prefetch(row) : 0u);
+    preCur[j] = kJoinAtFlush ? (Pre)0 : ((kFull || row * 32u + hl < n) ? sink.prefetch(row) : (Pre)0);
   }
 
 #pragma unroll 1
   for (int g = lastGroup; g >= 0; --g) {
     const uint32_t gNext = g > 0 ? (uint32_t)(g - 1) : 0u;
-    if (kWideNc) {
+    if (kJoinAtFlush) {
       ncNext = sink.prefetchGroup(gNext, hl);
-      // this group's 256 bytes: lane hl holds bytes [8 hl, 8 hl + 8); row j wants byte 32 j + hl
-      typedef uint32_t u32x2n __attribute__((ext_vector_type(2)));
-      *(__attribute__((address_space(3))) u32x2n*)(uintptr_t)(xposeNc + hl * 8u) = u32x2n{ncCur.x, ncCur.y};
-#pragma unroll
-      for (int j = 0; j < (int)kGroupRows; ++j) {
-        preCur[j] = *(const __attribute__((address_space(3))) uint8_t*)(uintptr_t)(xposeNc + (uint32_t)j * 32u + hl);
-      }
     } else {
 #pragma unroll
       for (int j = 0; j < (int)kGroupRows; ++j) {
         const uint32_t row = gNext * kGroupRows + j;
-        preNext[j] = (kFull || row * 32u + hl < n) ? sink.prefetch(row) : 0u;
+        preNext[j] = (kFull || row * 32u + hl < n) ? sink.prefetch(row) : (Pre)0;
       }
     }
     // ring maintenance
-    if (pendingChunk >= 0) {
-      *(LdsU4*)(uintptr_t)(ringBase | (((uint32_t)pendingChunk & 3u) * 512u + hl * 16u)) = u32x4{pending.x, pending.y, pending.z, pending.w};
-      pendingChunk = -1;
-    }
-    if (lowChunk > 0 && (uint32_t)lowChunk * kRingChunkWords + 512u > posw) {
-      --lowChunk;
-      const uint32_t off = (uint32_t)lowChunk * 512u + hl * 16u;
-      pending = (off < paddedBytes) ? *(const uint4*)(gwords + off) : make_uint4(0, 0, 0, 0);
-      pendingChunk = lowChunk;
+    if (kScalarPos && !kNoRing) posw = upper ? sHi : sLo;
+    if (!kNoRing) {
+      if (pendingChunk >= 0) {
+        *(LdsU4*)(uintptr_t)(ringBase | (((uint32_t)pendingChunk & 3u) * 512u + hl * 16u)) = u32x4{pending.x, pending.y, pending.z, pending.w};
+        pendingChunk = -1;
+      }
+      if (lowChunk > 0 && (uint32_t)lowChunk * kRingChunkWords + 512u > posw) {
+        --lowChunk;
+        const uint32_t off = (uint32_t)lowChunk * 512u + hl * 16u;
+        pending = (off < paddedBytes) ? *(const uint4*)(gwords + off) : make_uint4(0, 0, 0, 0);
+        pendingChunk = lowChunk;
+      }
     }
 #pragma unroll
     for (int j = (int)kGroupRows - 1; j >= 0; --j) {
@@ -369,7 +483,7 @@ __device__ __forceinline__ void decodeBlock(
       if (kFull) {
         const uint32_t e0 = stepFull();
         if (kWide) {
-          if (!kIdleUpper || !upper) sink.stageRow(xpose, (uint32_t)j, hl, e0, preCur[j]);
+          if (!kIdleUpper || !upper) sink.stageRow(xpose, (uint32_t)j, hl, e0);
         } else if (!kIdleUpper || !upper) {
           sink.store(row, e0, preCur[j]);
         }
@@ -379,8 +493,8 @@ __device__ __forceinline__ void decodeBlock(
         if (valid) sink.store(row, e0, preCur[j]);
       }
     }
-    if (kFull && kWide && (!kIdleUpper || !upper)) sink.flushGroup(xpose, (uint32_t)g, hl);
-    if (kWideNc) {
+    if (kJoinAtFlush) {
+      if (!kIdleUpper || !upper) sink.flushGroup(xpose, (uint32_t)g, hl, ncCur);
       ncCur = ncNext;
     } else {
 #pragma unroll
@@ -398,7 +512,7 @@ __global__ __launch_bounds__(decThreads(kTileBlocks)) void k_ans_decode(DecodeAr
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   // rings: 16 x 2 KiB at LDS offset 0 (2 KiB aligned), then the LUT, then the transposition buffers
   uint2* sLut = (uint2*)(smem + kTileBlocks * kRingBytes);
-  constexpr uint32_t kXpose = decXposeBytes(P, FT);
+  constexpr uint32_t kXpose = decXposeBytes(P, FT, kTileBlocks);
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
@@ -618,19 +732,26 @@ __global__ __launch_bounds__(decThreads(kTileBlocks)) void k_ans_decode(DecodeAr
   const uint32_t slot = hw < kTileBlocks ? hw : kTileBlocks - 1u;  // (single-block tiles: the idle upper half maps to slot 0 and touches nothing)
   const uint32_t xpose = ldsBase + kTileBlocks * kRingBytes + kLutBytes + slot * kXpose;
   const bool wide = kXpose != 0 && (((uintptr_t)a.out.ptr(b)) & 15u) == 0;  // wide stores need a 16-byte aligned output element
+  // both blocks of the wave small enough to be staged whole (wave-uniform)?
+  const uint32_t wFirst = __shfl(numWords, 0, 64);
+  const uint32_t wSecond = __shfl(numWords, 32, 64);
+  const bool noRing = DGPU_DEC_NORING && wFirst <= kRingBytes / 2u && wSecond <= kRingBytes / 2u;
+#define DGPU_DECODE_FULL(WIDE, IDLE, NORING) \
+  decodeBlock<P, FT, true, WIDE, IDLE, kCompact, NORING>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + slot * kRingBytes, sLut, sink, hl, upper)
   if (nFirst == kBlockSize && nSecond == kBlockSize) {
     if (wide) {
-      decodeBlock<P, FT, true, true, false, kCompact>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + slot * kRingBytes, sLut, sink, hl, upper);
+      if (noRing) DGPU_DECODE_FULL(true, false, true); else DGPU_DECODE_FULL(true, false, false);
     } else {
-      decodeBlock<P, FT, true, false, false, kCompact>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + slot * kRingBytes, sLut, sink, hl, upper);
+      if (noRing) DGPU_DECODE_FULL(false, false, true); else DGPU_DECODE_FULL(false, false, false);
     }
   } else if (nFirst == kBlockSize && nSecond == 0u) {
     // one full block in the wave (batches of single-block elements, odd block counts): fast path, idle upper half
     if (wide) {
-      decodeBlock<P, FT, true, true, true, kCompact>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + slot * kRingBytes, sLut, sink, hl, upper);
+      if (noRing) DGPU_DECODE_FULL(true, true, true); else DGPU_DECODE_FULL(true, true, false);
     } else {
-      decodeBlock<P, FT, true, false, true, kCompact>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + slot * kRingBytes, sLut, sink, hl, upper);
+      if (noRing) DGPU_DECODE_FULL(false, true, true); else DGPU_DECODE_FULL(false, true, false);
     }
+#undef DGPU_DECODE_FULL
   } else {
     const uint32_t maxN = nFirst > nSecond ? nFirst : nSecond;
     decodeBlock<P, FT, false, false, false, kCompact>(xpose, state, n, divUp(divUp(maxN, 32u), kGroupRows), gwords, numWords, smem, ldsBase + slot * kRingBytes, sLut, sink, hl, upper);

@@ -375,13 +375,31 @@ __device__ __forceinline__ uint32_t encodeRows(
   uint32_t state = kStartState;
   uint32_t outOff = 0;
   uint32_t spilled = 0;
+  // Full blocks (DGPU_ENC_SCALAR_POS): the write positions of the two halves are wave-uniform, so they live in two
+  // SGPRs as LDS WORD addresses (stage base folded in, advanced by s_bcnt1 of the ballot halves); an emitting
+  // lane's slot is v_mbcnt_lo + v_mbcnt_hi over the 64-bit ballot (lower half: its rank among the emitters;
+  // upper half: rank + emitters of the lower half) plus one v_mad_i32_i24 that moves the upper half onto its own
+  // position -- no 64-bit shift to pick the half, no per-lane popcounts (as in the decoder, kernels_decode.h).
+  // MEASURED SLOWER and therefore off: 256 x 1 MiB Zipf bytes encode 169.8 -> 177.3 us (bf16 unchanged, HBM-bound).
+  // The row loop is bound by its dependent chain, and the hop VALU -> SALU -> VALU (v_cmp, s_bcnt1, s_sub,
+  // v_mad_i32_i24) is longer than the all-VALU chain it replaces, although it is two VALU instructions shorter.
+#ifndef DGPU_ENC_SCALAR_POS
+#define DGPU_ENC_SCALAR_POS 0
+#endif
+  constexpr bool kScalarPos = kFull && DGPU_ENC_SCALAR_POS;
+  const uint32_t baseLo = __builtin_amdgcn_readlane(stageBase, 0) >> 1;
+  const uint32_t baseHi = __builtin_amdgcn_readlane(stageBase, 32) >> 1;
+  uint32_t fLo = baseLo, fHi = baseHi;
+  int upperSel = upper ? 1 : 0;
+  asm volatile("" : "+v"(upperSel));  // a VGPR operand of the multiply-add, not a select to be folded into it
 
   // Called every kFlushRows rows: make room for the next kFlushRows rows.
   auto makeRoom = [&]() {
     if (!kSpill) return;
-    const uint32_t o0 = __builtin_amdgcn_readlane(outOff, 0);
-    const uint32_t o1 = __builtin_amdgcn_readlane(outOff, 32);
+    const uint32_t o0 = kScalarPos ? fLo - baseLo : __builtin_amdgcn_readlane(outOff, 0);
+    const uint32_t o1 = kScalarPos ? fHi - baseHi : __builtin_amdgcn_readlane(outOff, 32);
     if ((o0 > o1 ? o0 : o1) + kFlushRows * 32u <= encStageCap(P, true, FT)) return;  // wave-uniform
+    if (kScalarPos) outOff = upper ? o1 : o0;
     // whole 16-byte vectors go to the spill slot, the (< 8 word) rest moves to the front
     uint32_t nvec = outOff >> 3;
     // cannot happen with a table made from this data's histogram; keeps a
@@ -398,6 +416,10 @@ __device__ __forceinline__ uint32_t encodeRows(
     if (hl < rem) *(LdsU16e*)(uintptr_t)(stageBase + 2u * hl) = t;
     spilled += nvec * 8u;
     outOff = rem;
+    if (kScalarPos) {
+      fLo = baseLo + (o0 & 7u);
+      fHi = baseHi + (o1 & 7u);
+    }
   };
 
   // Generic step (partial blocks): predicated, emission under a branch.
@@ -425,6 +447,23 @@ __device__ __forceinline__ uint32_t encodeRows(
   auto stepFullC = [&](const uint4 e) {
     const bool write = state >= e.x;
     const uint64_t vote = __ballot(write);
+    if (kScalarPos) {
+      const uint32_t vLo = (uint32_t)vote, vHi = (uint32_t)(vote >> 32);
+      const uint32_t fLoOld = fLo, fHiOld = fHi;
+      fLo += (uint32_t)__popc(vLo);
+      fHi += (uint32_t)__popc(vHi);
+      // emitters below me in the wave: lower half = my rank, upper half = rank + emitters of the lower half
+      uint32_t t = __builtin_amdgcn_mbcnt_hi(vHi, __builtin_amdgcn_mbcnt_lo(vLo, 0u));
+      // lower: fLoOld + rank; upper: fHiOld + rank = fLoOld + (rank + emittersLo) + (fHiOld - fLo)
+      t = (uint32_t)(__mul24(upperSel, (int)(fHiOld - fLo)) + (int)t);
+      asm volatile("" : "+v"(t));  // keep the scalar position in the add-shift below (one SGPR operand per VALU op)
+      const uint32_t addr = write ? ((t + fLoOld) << 1) : dummyAddr;
+      *(LdsU16e*)(uintptr_t)addr = (uint16_t)state;
+      state = write ? (state >> kEncodedBits) : state;
+      const uint32_t div = __umulhi(state, e.y) >> (e.w >> 24);
+      state = __umul24(div, e.w) + state + e.z;
+      return;
+    }
     const uint32_t vh = upper ? (uint32_t)(vote >> 32) : (uint32_t)vote;
     const uint32_t idx = outOff + __popc(vh & laneMaskLt);
     const uint32_t addr = write ? stageBase + 2u * idx : dummyAddr;
@@ -514,6 +553,7 @@ __device__ __forceinline__ uint32_t encodeRows(
   // waves of a workgroup share their CU's L1), no L2 write-back.
   spilledOut = spilled;
   stateOut = state;
+  if (kScalarPos) return upper ? fHi - baseHi : fLo - baseLo;
   return outOff;
 }
 

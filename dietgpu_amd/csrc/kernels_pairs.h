@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64) void k_ans_encode_pair(EncodeArgs a) {
 // ---------------------------------------------------------------------------
 // Decoder.  LDS: two 2 KiB rings (2 KiB aligned, at offset 0), two compact LUTs, two store buffers.
 __host__ __device__ constexpr uint32_t decPairLdsBytes(int P, uint32_t ft) {
-  return 2u * kRingBytes + 2u * (4u << P) + 2u * decXposeBytes(P, ft);
+  return 2u * kRingBytes + 2u * (4u << P) + 2u * decXposeBytes(P, ft, 1u);
 }
 
 // grid = ceil(B / 2) workgroups of one wavefront.  The host guarantees that every output capacity is <= 4096
@@ -182,7 +182,7 @@ template <int P, uint32_t FT>
 __global__ __launch_bounds__(64) void k_ans_decode_pair(DecodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr uint32_t kLutBytes = 4u << P;
-  constexpr uint32_t kXpose = decXposeBytes(P, FT);
+  constexpr uint32_t kXpose = decXposeBytes(P, FT, 1u);
   const uint32_t lane = threadIdx.x;
   const bool upper = lane >= 32u;
   const uint32_t hl = lane & 31u;

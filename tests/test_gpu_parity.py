@@ -303,6 +303,35 @@ def test_ans_worst_case_block(dg, prob_bits):
     assert status.all() and (outs[0] == x).all()
 
 
+@pytest.mark.parametrize("prob_bits", [9, 10, 11])
+def test_decoder_staging_modes_raw(dg, prob_bits):
+    # The decoder stages a wave's two blocks WHOLE when both have <= 1024 compressed words and goes through
+    # the 2 KiB word ring otherwise (wave-uniform choice): one element holds waves of both kinds and
+    # waves that mix a compressible with an incompressible block; 16-block and small tiles, a partial tail.
+    rng = np.random.default_rng(4242 + prob_bits)
+
+    def blocks(kinds, tail=0):
+        parts = []
+        for k in kinds:
+            if k == "c":  # a few symbols: ~1.5 bits each
+                parts.append(rng.choice(np.array([0, 1, 2, 3], np.uint8), 4096, p=[0.7, 0.2, 0.07, 0.03]))
+            else:         # uniform bytes: far above the table's average code length
+                parts.append(rng.integers(0, 256, 4096, dtype=np.uint8))
+        if tail:
+            parts.append(rng.integers(0, 4, tail, dtype=np.uint8))
+        return np.concatenate(parts)
+
+    xs = [blocks("ccrrcrrc" * 5, 777), blocks("ccrcrr"), blocks("cc"), blocks("rr"), blocks("c" * 33, 4095)]
+    got = gpu_ans_encode(dg, xs, prob_bits)
+    for x, g in zip(xs, got):
+        want = O.ans_encode(x, prob_bits)
+        assert g.size == want.size and (g == want).all()
+    outs, status, osz = gpu_ans_decode(dg, got, [x.size for x in xs], prob_bits)
+    assert status.all() and osz.tolist() == [x.size for x in xs]
+    for x, o in zip(xs, outs):
+        assert (o == x).all()
+
+
 # ---------------------------------------------------------------- float codec
 @pytest.mark.parametrize("ft", [O.FLOAT16, O.BFLOAT16, O.FLOAT32])
 @pytest.mark.parametrize("prob_bits", [9, 10])
