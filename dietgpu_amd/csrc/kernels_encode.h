@@ -624,6 +624,15 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
   for (uint32_t t = blockIdx.x + (tid + 1u) * gridDim.x; t < a.numTickets; t += kThreads * gridDim.x) {
     (void)claimTry(t);  // later tickets: result looked up when the ticket comes up
   }
+#ifdef DGPU_ENC_STAGGER_UNITS
+  // Experiment (off): the workgroups that share a CU (blockIdx i, i + 256, ...) start a fraction of a tile time
+  // apart (after their claims are out, so nobody takes their tiles over).  The first tile of a workgroup takes
+  // 44 K cycles, the later ones 29-32 K (tools/phase_timing.py), which looked like "everybody loads, then
+  // everybody computes"; staggering by 2 / 4 / 8 K cycles per slot changes nothing / +1 / +4 us: the first
+  // round is slower because all six workgroups of a CU share the memory system then -- the kernel moves its
+  // bytes at the fabric rate either way (profiles/r02_ab_encoder_stagger.txt).
+  for (uint32_t i = 0, n = (blockIdx.x >> 8) * DGPU_ENC_STAGGER_UNITS; i < n; ++i) __builtin_amdgcn_s_sleep(32);
+#endif
   for (uint32_t ticket0 = blockIdx.x; ticket0 < a.numTickets; ticket0 += gridDim.x) {
     const uint32_t tile0 = ticket0 / B;
     const uint32_t b = ticket0 - tile0 * B;

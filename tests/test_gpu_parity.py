@@ -332,6 +332,41 @@ def test_decoder_staging_modes_raw(dg, prob_bits):
         assert (o == x).all()
 
 
+def _block_words(ans_archive):
+    """compressed u16 words of every block of an ANS archive (ANSCoalescedHeader, GpuANSUtils.cuh:67-229)"""
+    hdr = ans_archive[:32].view(np.uint32)
+    nb = int(hdr[1])
+    off = 32 + 512 + 128 * nb
+    bw = ans_archive[off : off + 8 * nb].view(np.uint32).reshape(nb, 2)
+    return bw[:, 0] & 0xFFFF
+
+
+def test_decoder_staging_boundary(dg):
+    # 17 nearly equiprobable symbols = a little over 4 bits per symbol: every block has 1024 .. 1027 words, i.e.
+    # sits on or just past the whole-block staging limit (1024 words), so waves of both kinds alternate
+    rng = np.random.default_rng(777)
+    p = np.array([1.3, 1.2, 1.1] + [1.0] * 11 + [0.9, 0.8, 0.7])
+    x = rng.choice(17, 4096 * 96, p=p / p.sum()).astype(np.uint8) * 13 + 3
+    w = _block_words(O.ans_encode(x, 10))
+    assert (w <= 1024).any() and (w > 1024).any() and (np.abs(w.astype(int) - 1024) <= 2).any(), (w.min(), w.max())
+    got = gpu_ans_encode(dg, [x], 10)
+    want = O.ans_encode(x, 10)
+    assert got[0].size == want.size and (got[0] == want).all()
+    outs, status, _ = gpu_ans_decode(dg, got, [x.size], 10)
+    assert status.all() and (outs[0] == x).all()
+    # the same exponent bytes inside bf16 words (float join at the flush on both staging paths)
+    words = (x.astype(np.uint16) << 7) | rng.integers(0, 128, x.size, dtype=np.uint16) | (rng.integers(0, 2, x.size, dtype=np.uint16) << 15)
+    t = words_to_tensor(O.BFLOAT16, words)
+    comp, sizes, _ = dg.compress_data(True, [t], False, prob_bits=10)
+    n = int(sizes[0].item())
+    wantf = O.float_compress(O.BFLOAT16, words, 10)
+    assert n == wantf.size and (comp[0, :n].cpu().numpy() == wantf).all()
+    out = torch.empty_like(t)
+    status = torch.zeros((1,), dtype=torch.uint8, device=DEV)
+    dg.decompress_data(True, [comp[0, :n]], [out], False, None, status, None, prob_bits=10)
+    assert status.cpu().numpy().all() and (tensor_to_words(O.BFLOAT16, out) == words).all()
+
+
 # ---------------------------------------------------------------- float codec
 @pytest.mark.parametrize("ft", [O.FLOAT16, O.BFLOAT16, O.FLOAT32])
 @pytest.mark.parametrize("prob_bits", [9, 10])

@@ -13,8 +13,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-DBG = "/tmp/libdietgpu_amd_dbg.so"
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+DBG = os.environ.get("DGPU_PT_LIB", "/tmp/libdietgpu_amd_dbg.so")  # DGPU_PT_LIB: a prebuilt -DDGPU_PHASE_TIMING library
+if "DGPU_PT_LIB" not in os.environ:
+  subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                        "-DDGPU_PHASE_TIMING"] + os.environ.get("DGPU_EXTRA_FLAGS", "").split() + ["-o", DBG, os.path.join(ROOT, "dietgpu_amd/csrc/capi.hip")])
 import dietgpu_amd.build as b
 b.LIB_PATH = DBG
@@ -74,6 +75,16 @@ for w in np.unique(wg):
     lasts.append(r[-1, 5] - t0)
     counts.append(len(r))
     gaps += list(r[1:, 0] - r[:-1, 5])
+# rows phase and total by the tile's ordinal within its workgroup (0 = the tile a workgroup starts with)
+by_ord = {}
+for w in np.unique(wg):
+    r = t[wg == w]
+    r = r[np.argsort(r[:, 0])]
+    for k in range(len(r)):
+        by_ord.setdefault(k, []).append((r[k, 2] - r[k, 1], r[k, 4] - r[k, 3], r[k, 5] - r[k, 0]))
+for k in sorted(by_ord):
+    a = np.array(by_ord[k], dtype=np.float64)
+    print(f"    tile #{k} of its workgroup: n {len(a)}  rows mean {a[:,0].mean():.0f} p95 {np.percentile(a[:,0],95):.0f}  lookback mean {a[:,1].mean():.0f}  total mean {a[:,2].mean():.0f}")
 wgspan = np.array(lasts) - np.array(firsts)
 print(f"  per-WG span (first tile start -> last tile end): mean {wgspan.mean():.0f} p50 {np.median(wgspan):.0f} p95 {np.percentile(wgspan,95):.0f} max {wgspan.max():.0f}")
 for ntiles in sorted(set(counts)):
