@@ -1175,8 +1175,14 @@ int launchDecodePF(const DecodeArgs& a, uint32_t tileBlocks, dim3 grid, hipStrea
     DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode<P, FT, kDecBlocksPerSmallTile>), grid, dim3(kDecBlocksPerSmallTile * 32u),
                 decLdsBytes(P, FT, kDecBlocksPerSmallTile), stream, a);
   } else {
+    // DGPU_DEC_LDS_PAD (experiment knob): extra dynamic LDS per workgroup, i.e. fewer workgroups per CU -- the
+    // occupancy scaling of the 16-block decoder (tools/occupancy_scaling.sh)
+    static const uint32_t pad = [] {
+      const char* e = getenv("DGPU_DEC_LDS_PAD");
+      return e ? (uint32_t)atoi(e) : 0u;
+    }();
     DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode<P, FT, kDecBlocksPerTile>), grid, dim3(kDecBlocksPerTile * 32u),
-                decLdsBytes(P, FT, kDecBlocksPerTile), stream, a);
+                decLdsBytes(P, FT, kDecBlocksPerTile) + pad, stream, a);
   }
   DGPU_HIP(hipGetLastError());
   return DGPU_OK;

@@ -5,21 +5,28 @@
 // (dietgpu/float/GpuFloatDecompress.cuh:320-521).  Organisation for wave64:
 //
 //   * one wave64 decodes TWO 4 KiB blocks (lanes 0-31 / 32-63), one 64-bit
-//     ballot per row, each half counting its own 32-bit slice from the top
-//     lane down (the mirror of the encoder's ascending emission order);
-//   * integer VALU ops issue at ~4 cycles per wave-instruction per SIMD on this
-//     chip (tools/microbench/valu_rate.hip), so the row loop is built to
-//     minimise VALU instructions and to keep many waves resident:
+//     ballot per row; readers take their words from the top of the block down
+//     in descending column order (the mirror of the encoder's ascending
+//     emission order);
+//   * the row loop is a dependent chain -- LUT entry (LDS), state update,
+//     ballot, word address, word (LDS), renormalise -- and costs what that
+//     chain's latency costs divided by the wavefronts that fit (DESIGN.md
+//     section 3: extra instructions beside the chain are nearly free), so:
 //       - the decode LUT holds 64-bit entries {pdf | sym << 24, x - cdf}: the
 //         state update is one shift + one v_mad_u32_u24, and the symbol is
-//         already in the top byte where the float join wants it;
-//       - compressed words are staged through a 2 KiB LDS ring per block
-//         (4 x 512-byte chunks, refilled one 8-row group ahead) instead of a
-//         worst-case 5 KiB stage, so LDS no longer caps occupancy;
-//       - each decoded element is joined with its non-compressed byte(s)
-//         (prefetched a group ahead, independent of the rANS state) and stored
-//         straight to HBM: 2 VALU ops for bf16 (v_lshl_or + v_alignbit, stored
-//         with a d16_hi short store), 1 for fp16, 2 for fp32.
+//         already in the top byte where the write-out wants it;
+//       - compressed words sit in a 2 KiB LDS region per block: the whole
+//         block when both blocks of the wave have <= 1024 words, else a ring of
+//         4 x 512-byte chunks refilled one 8-row group ahead -- not a
+//         worst-case 5 KiB stage, so LDS does not cap occupancy harder;
+//       - the unread-word positions of the two halves are wave-uniform and live
+//         in SGPRs (s_bcnt1 of the ballot halves); a lane's rank comes from
+//         v_mbcnt_lo/hi over the ballot;
+//       - aligned 16-bit float outputs: a row leaves {sym, 0} in a 512-byte LDS
+//         buffer (ds_write_b16_d16_hi, no VALU); every 8 rows a lane joins its
+//         8 consecutive words with the 8 non-compressed bytes it fetched with
+//         ONE load and stores 16 bytes (RowSink::flushGroup).  Otherwise the
+//         per-row sinks join and store one element per lane and row.
 #pragma once
 
 #include "format.h"
