@@ -658,6 +658,34 @@ int uploadParams(
   return DGPU_OK;
 }
 
+
+// A pointer batch whose addresses form an arithmetic progression and whose sizes are all equal IS a stride batch
+// (the rows of one tensor, the rows of the output matrix the tensor API allocates, any batch of one): it needs no
+// parameter block on the device at all -- no cache lookup, and no blit + event records when the cache would miss
+// (+9 us per call).  sizesOnOut: the sizes are output capacities (decode) rather than input sizes (encode).
+bool progression(const std::vector<uint64_t>& p, uint64_t* stride) {
+  *stride = p.size() > 1 ? p[1] - p[0] : 0;
+  for (size_t i = 1; i < p.size(); ++i) {
+    if (p[i] - p[i - 1] != *stride) return false;
+  }
+  return !p.empty();
+}
+#ifndef DGPU_STRIDE_DETECT
+#define DGPU_STRIDE_DETECT 1
+#endif
+bool asStrideViews(const HostParams& hp, bool sizesOnOut, BatchView* in, BatchView* out) {
+  if (!DGPU_STRIDE_DETECT || !hp.inBytes.empty() || hp.inPtrs.size() != hp.outPtrs.size()) return false;
+  uint64_t inStride = 0, outStride = 0;
+  if (!progression(hp.inPtrs, &inStride) || !progression(hp.outPtrs, &outStride)) return false;
+  uint32_t u = hp.sizes.empty() ? 0u : hp.sizes[0];
+  for (uint32_t sz : hp.sizes) {
+    if (sz != u) return false;
+  }
+  *in = viewStride((const void*)(uintptr_t)hp.inPtrs[0], inStride, sizesOnOut ? 0u : u);
+  *out = viewStride((const void*)(uintptr_t)hp.outPtrs[0], outStride, sizesOnOut ? u : 0u);
+  return true;
+}
+
 // ---------------------------------------------------------------------------
 // Launch sequences
 // ---------------------------------------------------------------------------
@@ -1104,7 +1132,9 @@ int ansEncodeImpl(
   TempArena arena(temp_dev, tempBytes, streamLease);
   ParamLease lease;
   BatchView in, out;
-  if (hp) {
+  if (hp && asStrideViews(*hp, false, &in, &out)) {
+    // (nothing to upload)
+  } else if (hp) {
     const uint64_t *inP = nullptr, *outP = nullptr;
     const uint32_t* sz = nullptr;
     int rc = uploadParams(lease, stream, *hp, &inP, &outP, &sz);
@@ -1142,12 +1172,16 @@ int floatCompressImpl(
   StreamLease streamLease(stream);
   TempArena arena(temp_dev, tempBytes, streamLease);
   ParamLease lease;
-  const uint64_t *inP = nullptr, *outP = nullptr;
-  const uint32_t* sz = nullptr;
-  int rc = uploadParams(lease, stream, hp, &inP, &outP, &sz);
-  if (rc) return rc;
-  BatchView in = viewPointers(inP, sz, 0);
-  BatchView out = viewPointers(outP, nullptr, 0);
+  BatchView in, out;
+  int rc = DGPU_OK;
+  if (!asStrideViews(hp, false, &in, &out)) {
+    const uint64_t *inP = nullptr, *outP = nullptr;
+    const uint32_t* sz = nullptr;
+    rc = uploadParams(lease, stream, hp, &inP, &outP, &sz);
+    if (rc) return rc;
+    in = viewPointers(inP, sz, 0);
+    out = viewPointers(outP, nullptr, 0);
+  }
 
   // No exponent plane in temp memory: the encoder splits the float words itself.
   uint32_t uniformSize = 0;
@@ -1214,7 +1248,9 @@ int decodeImpl(
   ParamLease lease;
   BatchView in, out;
   const uint32_t* inBytes_dev = nullptr;
-  if (hp) {
+  if (hp && asStrideViews(*hp, true, &in, &out)) {
+    // (nothing to upload)
+  } else if (hp) {
     const uint64_t *inP = nullptr, *outP = nullptr;
     const uint32_t* cap = nullptr;
     int rc = uploadParams(lease, stream, *hp, &inP, &outP, &cap, &inBytes_dev);
