@@ -332,6 +332,62 @@ def test_decoder_staging_modes_raw(dg, prob_bits):
         assert (o == x).all()
 
 
+def test_pointer_batches_in_arithmetic_progression(dg):
+    # A pointer batch whose addresses form an arithmetic progression with equal sizes is handled as a stride batch
+    # (no parameter block): ascending rows, DESCENDING rows (the stride wraps around 2^64), the same row four times
+    # (stride 0), a batch of one -- and the same rows in scrambled order (a genuine pointer list) for comparison.
+    rng = np.random.default_rng(99)
+    n = 4096 * 5 + 123
+    words = (rng.standard_normal((6, n)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    t = torch.from_numpy(words.view(np.int16)).to(DEV).view(torch.bfloat16)
+    want = [O.float_compress(O.BFLOAT16, words[i], 10) for i in range(6)]
+    for order in ([0, 1, 2, 3, 4, 5], [5, 4, 3, 2, 1, 0], [2, 2, 2, 2], [3], [0, 2, 4], [4, 0, 5, 1]):
+        ts = [t[i] for i in order]
+        comp, sizes, _ = dg.compress_data(True, ts, False, prob_bits=10)
+        hs = sizes.cpu().numpy()
+        hc = comp.cpu().numpy()
+        arch = []
+        for k, i in enumerate(order):
+            assert hs[k] == want[i].size and (hc[k, : hs[k]] == want[i]).all(), (order, k)
+            arch.append(comp[k, : hs[k]])
+        # decode into the rows of one output tensor, in the same (possibly descending) order
+        out = torch.zeros((6, n), dtype=torch.bfloat16, device=DEV)
+        outs = [out[i] for i in order] if len(set(order)) == len(order) else [torch.empty_like(t[0]) for _ in order]
+        status = torch.zeros((len(order),), dtype=torch.uint8, device=DEV)
+        dg.decompress_data(True, arch, outs, False, None, status, None, prob_bits=10)
+        assert status.cpu().numpy().all()
+        for k, i in enumerate(order):
+            assert (tensor_to_words(O.BFLOAT16, outs[k]) == words[i]).all(), (order, k)
+
+
+@pytest.mark.parametrize("workload", ["bf16", "u8"])
+def test_stride_detected_batches_through_the_c_abi(dg, workload):
+    # bench.Codec hands the C ABI the rows of one tensor as pointer lists (unbounded decode entry points): both
+    # directions take the stride path; then the same with two elements swapped (parameter block).  Archives of
+    # every row against the oracle, round trip exact.
+    import bench
+
+    data, ft, _, P, _ = bench.make_workload(workload, 12, 4321, DEV, 4096 * 3 + 640)
+    codec = bench.Codec(dg, data, ft, P)
+    for scattered in (False, True):
+        if scattered:
+            codec.scatter_pointers()
+        codec.sizes.zero_()
+        codec.out.zero_()
+        codec.step()
+        codec.verify()
+        hs = codec.sizes.cpu().numpy()
+        hc = codec.comp.cpu().numpy()
+        rows = data.view(torch.uint8).cpu().numpy().reshape(12, -1)
+        for k in range(12):
+            r = k if not scattered or k > 1 else 1 - k  # element k of the call is row r
+            if ft:
+                want = O.float_compress(ft, rows[r].view(np.uint16), P)
+            else:
+                want = O.ans_encode(rows[r], P)
+            assert hs[k] == want.size and (hc[r, : hs[k]] == want).all(), (workload, scattered, k)
+
+
 def _block_words(ans_archive):
     """compressed u16 words of every block of an ANS archive (ANSCoalescedHeader, GpuANSUtils.cuh:67-229)"""
     hdr = ans_archive[:32].view(np.uint32)
