@@ -75,7 +75,9 @@ class KernelTimer {
     ProfState& p = prof();
     if (!p.enabled) return;
     span_.name = name;
-    if (hipEventCreate(&span_.start) != hipSuccess || hipEventCreate(&span_.stop) != hipSuccess) return;
+    // no system-scope fence at the events: it would write the L2 back around every kernel that is being timed
+    if (hipEventCreateWithFlags(&span_.start, hipEventDisableSystemFence) != hipSuccess ||
+        hipEventCreateWithFlags(&span_.stop, hipEventDisableSystemFence) != hipSuccess) return;
     (void)hipEventRecord(span_.start, stream_);
     active_ = true;
   }
@@ -458,9 +460,11 @@ class ParamCache {
       victim->cap = cap;
     }
     if (!victim->copied) {
-      e = hipEventCreateWithFlags(&victim->copied, hipEventDisableTiming);
+      // ordering only (a later stream's kernels after the blit; the host asking whether the call is done): no
+      // system-scope fence, which costs a cache write-back per record and slows the kernels that follow
+      e = hipEventCreateWithFlags(&victim->copied, hipEventDisableTiming | hipEventDisableSystemFence);
       if (e != hipSuccess) return e;
-      e = hipEventCreateWithFlags(&victim->released, hipEventDisableTiming);
+      e = hipEventCreateWithFlags(&victim->released, hipEventDisableTiming | hipEventDisableSystemFence);
       if (e != hipSuccess) return e;
     }
     memcpy(victim->host, block, bytes);
