@@ -76,10 +76,9 @@ typedef __attribute__((address_space(3))) uint16_t LdsU16w;
 typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4w LdsU4w;
 
-// {e0.b3 (symbol), r.b0 (non-compressed byte), e0.b1, e0.b0} in one v_perm_b32.  Only byte 0 of r is used, so the
-// byte loaded a group earlier needs no zero-extension when it is consumed (as (r << 16) | e0 the compiler
-// re-masked it with a v_and per row: the value crosses the loop edge as an i8, and the zero-extension is sunk
-// away from the load).
+// Per-row join (narrow path): {e0.b3 (symbol), r.b0 (non-compressed byte), e0.b1, e0.b0} in one v_perm_b32.
+// (The byte loaded a group earlier still costs one v_and per row here: it crosses the loop edge as an i8 and the
+// compiler sinks its zero-extension away from the load.  The wide path has no per-row byte at all.)
 #ifndef DGPU_DEC_PERM_JOIN
 #define DGPU_DEC_PERM_JOIN 1
 #endif
