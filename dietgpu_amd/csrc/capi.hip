@@ -568,19 +568,24 @@ BatchView viewPointers(const uint64_t* ptrs_dev, const uint32_t* sizes_dev, uint
 // atomic), so workgroups should be long; two per CU already saturate HBM.  With
 // a large batch that is a few long workgroups per element, with a single large
 // tensor up to 256 of them.
+// Raw bytes carry twice the symbols (LDS atomics, address arithmetic) per byte of traffic: three workgroups per CU
+// (256 x 1 MiB Zipf bytes: 53.9 -> 51.3 us; the exponent histogram loses 2 us with three).
 #ifndef DGPU_HIST_TARGET_WGS
 #define DGPU_HIST_TARGET_WGS 512
 #endif
-uint32_t histPartsFor(uint32_t B, uint32_t maxBytes) {
+#ifndef DGPU_HIST_TARGET_WGS_RAW
+#define DGPU_HIST_TARGET_WGS_RAW 768
+#endif
+uint32_t histPartsFor(uint32_t B, uint32_t maxBytes, bool raw) {
   const uint32_t bySize = divUp(std::max(maxBytes, 1u), 32u * 1024u);
-  const uint32_t byBatch = divUp((uint32_t)DGPU_HIST_TARGET_WGS, std::max(B, 1u));
+  const uint32_t byBatch = divUp((uint32_t)(raw ? DGPU_HIST_TARGET_WGS_RAW : DGPU_HIST_TARGET_WGS), std::max(B, 1u));
   return std::max(1u, std::min(std::min(bySize, byBatch), 256u));
 }
 // One or two large elements: the counts of an element's workgroups meet in 256 library-owned
 // atomic counters instead of per-workgroup partial histograms, so an element can be spread over
 // ~512 workgroups without the normalising workgroup having to sum 512 partial histograms (a single
 // 256 MiB tensor: 79 -> 52 us; more workgroups than that lose to contention on the counters).
-bool histAccumulates(uint32_t B, uint32_t maxBytes);
+bool histAccumulates(uint32_t B, uint32_t maxBytes, bool raw);
 uint32_t histPartsAccFor(uint32_t B, uint32_t maxBytes) {
   const uint32_t bySize = divUp(std::max(maxBytes, 1u), 64u * 1024u);
 #ifndef DGPU_HIST_ACC_WGS
@@ -831,11 +836,11 @@ uint32_t tilesFor(uint32_t maxSize) { return divUp(divUp(maxSize, kBlockSize), e
 
 uint32_t absentWorkgroupModulo();  // test hook, defined with the C ABI below
 
-bool histAccumulates(uint32_t B, uint32_t maxBytes) {
+bool histAccumulates(uint32_t B, uint32_t maxBytes, bool raw) {
 #ifndef DGPU_HIST_ACC_MAX_B
 #define DGPU_HIST_ACC_MAX_B 2
 #endif
-  return B <= (uint32_t)DGPU_HIST_ACC_MAX_B && histPartsAccFor(B, maxBytes) > histPartsFor(B, maxBytes);
+  return B <= (uint32_t)DGPU_HIST_ACC_MAX_B && histPartsAccFor(B, maxBytes) > histPartsFor(B, maxBytes, raw);
 }
 
 // Library-owned arrival counters for the histogram -> normalisation hand-off
@@ -1046,8 +1051,8 @@ int encodeCommon(
   n.inKernelConsumer = 0;
 
   if (!hist_dev) {
-    const bool accumulate = histAccumulates(B, maxSize * wordBytes);
-    dim3 grid(accumulate ? histPartsAccFor(B, maxSize * wordBytes) : histPartsFor(B, maxSize * wordBytes), B);
+    const bool accumulate = histAccumulates(B, maxSize * wordBytes, floatType == 0);
+    dim3 grid(accumulate ? histPartsAccFor(B, maxSize * wordBytes) : histPartsFor(B, maxSize * wordBytes, floatType == 0), B);
     uint32_t* histTemp = nullptr;
     if (!accumulate) {
       DGPU_ALLOC(ht, uint32_t, arena, (size_t)B * grid.x * kNumSymbols);
@@ -1449,7 +1454,7 @@ uint32_t dgpu_float_max_compressed_size(uint32_t ft, uint32_t n) {
 
 static size_t encodeTempBytes(uint32_t B, uint32_t maxBytes, uint32_t wordBytes, bool spills) {
   size_t tiles = std::max(tilesFor(maxBytes), 1u);
-  size_t parts = std::max<size_t>(histPartsFor(B, maxBytes * wordBytes), std::min<size_t>(tiles, kFusedMaxTiles));
+  size_t parts = std::max<size_t>(histPartsFor(B, maxBytes * wordBytes, true), std::min<size_t>(tiles, kFusedMaxTiles));
   size_t t = 0;
   t += alignUp((size_t)B * 4, kTempAlign);                                        // checksums
   t += alignUp((size_t)B * parts * kNumSymbols * 4, kTempAlign);                  // partial histograms
