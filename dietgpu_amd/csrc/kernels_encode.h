@@ -667,6 +667,7 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
     }
    for (uint32_t tile = tileLo; tile <= tile0; ++tile) {
     const uint32_t ticket = tile * B + b;
+    (void)ticket;  // only the phase-timing build uses it
 #elif DGPU_SCHEDULE == 1  // analysis only: UNSAFE unless every workgroup of the grid is resident
   for (uint32_t ticket = blockIdx.x; ticket < a.numTickets; ticket += gridDim.x) {
 #else
