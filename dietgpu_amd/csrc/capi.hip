@@ -18,6 +18,7 @@
 
 #include "format.h"
 #include "kernels_decode.h"
+#include "kernels_decode_mt.h"
 #include "kernels_encode.h"
 #include "kernels_encode_fused.h"
 #include "kernels_pairs.h"
@@ -1202,6 +1203,19 @@ int floatCompressImpl(
   return rc;
 }
 
+// DGPU_DEC_MT: the four-blocks-per-wavefront decoder for raw bytes (kernels_decode_mt.h); environment DGPU_DEC_MT=0
+// switches back to k_ans_decode's 16-block tiles (A/B runs)
+#ifndef DGPU_DEC_MT
+#define DGPU_DEC_MT 1
+#endif
+bool decodeMtEnabled() {
+  static const bool on = [] {
+    const char* e = getenv("DGPU_DEC_MT");
+    return e ? e[0] != '0' : (DGPU_DEC_MT != 0);
+  }();
+  return on;
+}
+
 template <int P, uint32_t FT>
 int launchDecodePF(const DecodeArgs& a, uint32_t tileBlocks, dim3 grid, hipStream_t stream) {
   if (DGPU_PAIRS && tileBlocks == kDecBlocksPerSingleTile) {
@@ -1217,6 +1231,19 @@ int launchDecodePF(const DecodeArgs& a, uint32_t tileBlocks, dim3 grid, hipStrea
   } else if (tileBlocks == kDecBlocksPerSmallTile) {
     DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode<P, FT, kDecBlocksPerSmallTile>), grid, dim3(kDecBlocksPerSmallTile * 32u),
                 decLdsBytes(P, FT, kDecBlocksPerSmallTile), stream, a);
+  } else if (FT == 0 && decodeMtEnabled()) {
+    // raw bytes, elements of more than 8 blocks: four blocks per wavefront, two row chains (kernels_decode_mt.h).
+    // A workgroup takes a slice of an element: as many 32-block rounds as leaves every CU its four workgroups.
+    if constexpr (FT == 0) {
+      const uint32_t maxBlocks = grid.x * kDecBlocksPerTile;
+      const uint32_t roundsPerElem = divUp(maxBlocks, kMtRoundBlocks);
+      const uint64_t slots = 4ull * numComputeUnits();
+      uint32_t rounds = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(roundsPerElem, (uint64_t)roundsPerElem * grid.y / slots));
+      while (rounds > 1u && roundsPerElem % rounds != 0u) --rounds;  // equal slices
+      const uint32_t sliceBlocks = rounds * kMtRoundBlocks;
+      DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode_mt<P, 0>), dim3(divUp(maxBlocks, sliceBlocks), grid.y), dim3(kMtThreads),
+                  decMtLdsBytes(P, 0), stream, a, sliceBlocks);
+    }
   } else {
     // DGPU_DEC_LDS_PAD (experiment knob): extra dynamic LDS per workgroup, i.e. fewer workgroups per CU -- the
     // occupancy scaling of the 16-block decoder (tools/occupancy_scaling.sh)
