@@ -129,7 +129,10 @@ __device__ __forceinline__ void decodeQuadFull(
       const uint64_t req = (uint64_t)mLo | ((uint64_t)mHi << 32);
       if (__builtin_amdgcn_inverse_ballot_w64(req)) {
         nextOff[c] -= (int)kMtChunkBytes;
-        pending[c] = *(const uint2*)(dataBase + (uint32_t)((int)dataOff[c] + nextOff[c]));  // chunks below the top one are whole
+        // (a VALID block stops two chunks below its data, see above; the clamp bounds what corrupt states or
+        // tables can make the decoder fetch: never more than 512 bytes below a block's data, i.e. inside the archive)
+        const int at = nextOff[c] > (int)(hl * 8u) - 2 * (int)kMtChunkBytes ? nextOff[c] : (int)(hl * 8u) - 2 * (int)kMtChunkBytes;
+        pending[c] = *(const uint2*)(dataBase + (uint32_t)((int)dataOff[c] + at));  // chunks below the top one are whole
         pendSlot[c] = ((uint32_t)nextOff[c] & (kMtRingBytes - 1u)) | ringBase[c];
       }
       pendMask[c] = req;

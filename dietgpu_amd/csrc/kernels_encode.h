@@ -356,7 +356,39 @@ struct ChunkSource<kFloat32> {  // 4-byte words: comp byte + 24 non-comp bits (u
 };
 
 // ---------------------------------------------------------------------------
-template <int P, uint32_t FT, bool kFull, bool kSpill>
+// kEntry8: the table in LDS holds PACKED 8-byte entries {magic, (2^P - pdf) | cdf' << 12 | shift << 24} (one
+// ds_read_b64 per symbol: half the LDS bytes of the 16-byte entry and a quarter of its bank-conflict surface);
+// the row then spends three more VALU instructions: the threshold test becomes the sign of
+// state + (2^P - pdf) << (31 - P)  (= state - (pdf << (31 - P)) + 2^31), and (2^P - pdf), cdf' are extracted.
+#ifndef DGPU_ENC_ENTRY8
+#define DGPU_ENC_ENTRY8 0
+#endif
+__host__ __device__ constexpr bool encEntry8(uint32_t ft, bool spill, uint32_t tileBlocks) {
+  return DGPU_ENC_ENTRY8 && ft == 0 && !spill && tileBlocks == kBlocksPerTile;
+}
+__device__ __forceinline__ uint2 packEntry8(const uint4 e) { return make_uint2(e.y, e.w | (e.z << 12)); }
+template <int P>
+__device__ __forceinline__ uint4 unpackEntry8(const uint2 p) {
+  const uint32_t q = p.y & 0xfffu;
+  return make_uint4(((1u << P) - q) << (kStateBits - P), p.x, (p.y >> 12) & 0xfffu, p.y & 0xff000fffu);
+}
+__device__ __forceinline__ uint2 ldsTableEntry8(uint32_t addr) {
+  typedef uint32_t u32x2e __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) u32x2e LdsU2e;
+  const u32x2e v = *(const LdsU2e*)(uintptr_t)addr;
+  return make_uint2(v.x, v.y);
+}
+
+// DGPU_ENC_EXEC_WRITE: the emitting lanes of a full-block row store under the row's ballot as execution mask (two
+// scalar moves) instead of every lane storing, the non-emitting ones to a scratch slot (one v_cndmask per row).
+#ifndef DGPU_ENC_EXEC_WRITE
+#define DGPU_ENC_EXEC_WRITE 0
+#endif
+__device__ __forceinline__ void stageWriteUnder(uint64_t vote, uint32_t addr, uint32_t state) {
+  asm volatile("s_mov_b64 exec, %2\n\tds_write_b16 %0, %1\n\ts_mov_b64 exec, -1" : : "v"(addr), "v"(state), "s"(vote) : "memory");
+}
+
+template <int P, uint32_t FT, bool kFull, bool kSpill, bool kEntry8 = false>
 __device__ __forceinline__ uint32_t encodeRows(
     const ChunkSource<FT>& src,
     uint32_t n,                           // symbols in this half's block (0 = idle half)
@@ -466,13 +498,37 @@ __device__ __forceinline__ uint32_t encodeRows(
     }
     const uint32_t vh = upper ? (uint32_t)(vote >> 32) : (uint32_t)vote;
     const uint32_t idx = outOff + __popc(vh & laneMaskLt);
-    const uint32_t addr = write ? stageBase + 2u * idx : dummyAddr;
-    *(LdsU16e*)(uintptr_t)addr = (uint16_t)state;
+    if (DGPU_ENC_EXEC_WRITE) {
+      stageWriteUnder(vote, stageBase + 2u * idx, state);
+    } else {
+      const uint32_t addr = write ? stageBase + 2u * idx : dummyAddr;
+      *(LdsU16e*)(uintptr_t)addr = (uint16_t)state;
+    }
     state = write ? (state >> kEncodedBits) : state;
     const uint32_t div = __umulhi(state, e.y) >> (e.w >> 24);
     state = __umul24(div, e.w) + state + e.z;
     outOff += __popc(vh);
   };
+  // the same step on a packed 8-byte entry
+  auto stepFullC8 = [&](const uint2 p) {
+    const uint32_t q = p.y & 0xfffu;
+    const uint32_t u = __umul24(q, 1u << (kStateBits - P)) + state;  // >= 2^31  <=>  state >= pdf << (31 - P)
+    const bool write = (int)u < 0;
+    const uint64_t vote = __ballot(write);
+    const uint32_t vh = upper ? (uint32_t)(vote >> 32) : (uint32_t)vote;
+    const uint32_t idx = outOff + __popc(vh & laneMaskLt);
+    if (DGPU_ENC_EXEC_WRITE) {
+      stageWriteUnder(vote, stageBase + 2u * idx, state);
+    } else {
+      const uint32_t addr = write ? stageBase + 2u * idx : dummyAddr;
+      *(LdsU16e*)(uintptr_t)addr = (uint16_t)state;
+    }
+    state = write ? (state >> kEncodedBits) : state;
+    const uint32_t div = __umulhi(state, p.x) >> (p.y >> 24);
+    state = __umul24(div, q) + state + ((p.y >> 12) & 0xfffu);
+    outOff += __popc(vh);
+  };
+  static_assert(!kEntry8 || !DGPU_ENC_SCALAR_POS, "");
   if (kFull) {
     // chunks of 16 rows (8 for fp32); chunk c+1 is in flight in registers while chunk c is
     // consumed from the LDS ring (same wave writes and reads it: LDS ops of one
@@ -498,13 +554,26 @@ __device__ __forceinline__ uint32_t encodeRows(
       constexpr int kSymAhead = DGPU_ENC_SYM_AHEAD;
       static_assert(kSymAhead > kAhead && kSymAhead <= (int)kChunkRows, "a symbol slot is reused only after its table load was issued");
       auto symAddr = [&](int r) -> uint32_t {
-        uint32_t t = tableLds + ((uint32_t)ring[r * 32 + hl] << 4);
+        uint32_t t = tableLds + ((uint32_t)ring[r * 32 + hl] << (kEntry8 ? 3 : 4));
         asm volatile("" : "+v"(t));  // keep the scaled address; do not re-derive it (with a mask) at the use
         return t;
       };
       uint32_t toff[kSymAhead];
 #pragma unroll
       for (int r = 0; r < kSymAhead; ++r) toff[r] = symAddr(r);
+      if constexpr (kEntry8) {
+        uint2 e[kAhead];
+#pragma unroll
+        for (int r = 0; r < kAhead; ++r) e[r] = ldsTableEntry8(toff[r]);
+#pragma unroll
+        for (int r = 0; r < (int)kChunkRows; ++r) {
+          if (r % kFlushRows == 0) makeRoom();
+          const uint2 cur_e = e[r % kAhead];
+          if (r + kAhead < (int)kChunkRows) e[r % kAhead] = ldsTableEntry8(toff[(r + kAhead) % kSymAhead]);
+          if (r + kSymAhead < (int)kChunkRows) toff[r % kSymAhead] = symAddr(r + kSymAhead);
+          stepFullC8(cur_e);
+        }
+      } else {
       uint4 e[kAhead];
 #pragma unroll
       for (int r = 0; r < kAhead; ++r) e[r] = ldsTableEntry(toff[r]);
@@ -515,6 +584,7 @@ __device__ __forceinline__ uint32_t encodeRows(
         if (r + kAhead < (int)kChunkRows) e[r % kAhead] = ldsTableEntry(toff[(r + kAhead) % kSymAhead]);
         if (r + kSymAhead < (int)kChunkRows) toff[r % kSymAhead] = symAddr(r + kSymAhead);
         stepFullC(cur_e);
+      }
       }
     }
   } else {
@@ -536,14 +606,18 @@ __device__ __forceinline__ uint32_t encodeRows(
 #pragma unroll
       for (uint32_t j = 0; j < kFlushRows; ++j) {
         const uint32_t i = (row0 + j) * 32u + hl;
-        taddr[j] = tableLds + ((src.splitAt(i, word[j], i < n) & 0xffu) << 4);
+        taddr[j] = tableLds + ((src.splitAt(i, word[j], i < n) & 0xffu) << (kEntry8 ? 3 : 4));
       }
-      uint4 ent[2] = {ldsTableEntry(taddr[0]), ldsTableEntry(taddr[1])};
+      auto entryAt = [&](uint32_t addr) -> uint4 {
+        if (kEntry8) return unpackEntry8<P>(ldsTableEntry8(addr));
+        return ldsTableEntry(addr);
+      };
+      uint4 ent[2] = {entryAt(taddr[0]), entryAt(taddr[1])};
 #pragma unroll
       for (uint32_t j = 0; j < kFlushRows; ++j) {
         const uint32_t i = (row0 + j) * 32u + hl;
         const uint4 cur_e = ent[j % 2u];
-        if (j + 2u < kFlushRows) ent[j % 2u] = ldsTableEntry(taddr[j + 2u]);
+        if (j + 2u < kFlushRows) ent[j % 2u] = entryAt(taddr[j + 2u]);
         if (row0 + j < maxRows) step(cur_e, i < n);  // uniform condition
       }
     }
@@ -562,6 +636,7 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
   constexpr uint32_t kThreads = encThreads(kTB);
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr uint32_t kCap = encStageCap(P, kSpill, FT);
+  constexpr bool kEntry8 = encEntry8(FT, kSpill, kTB);
   // bookkeeping sits BELOW the stages so that a stage overrun (only possible
   // without spilling, with a caller-supplied histogram that does not match the
   // data) can never reach it
@@ -726,7 +801,11 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
     }
 #endif
 
-    for (uint32_t i = tid; i < kNumSymbols; i += kThreads) sTable[i] = a.encTable[b * kNumSymbols + i];
+    if constexpr (kEntry8) {
+      for (uint32_t i = tid; i < kNumSymbols; i += kThreads) ((uint2*)sTable)[i] = packEntry8(a.encTable[b * kNumSymbols + i]);
+    } else {
+      for (uint32_t i = tid; i < kNumSymbols; i += kThreads) sTable[i] = a.encTable[b * kNumSymbols + i];
+    }
     ldsBarrier();
     DGPU_PHASE(1);
 
@@ -781,7 +860,7 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
     uint32_t words;        // words left in the LDS stage
     uint32_t spilled = 0;  // words already in the spill slot
     if (waveFull || waveHalf) {
-      words = encodeRows<P, FT, true, kSpill>(src, n, kRowsPerBlock, sTable, tableLds, stageLds, dummyLds,
+      words = encodeRows<P, FT, true, kSpill, kEntry8>(src, n, kRowsPerBlock, sTable, tableLds, stageLds, dummyLds,
                                               sRing + slot * 512u, hl, upper, spillSlot, spilled, state);
     } else {
       // rows needed by the larger of the two halves (uniform)
@@ -790,7 +869,7 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
         uint32_t beginA = firstBlockOfWave * kBlockSize;
         nA = size - beginA < kBlockSize ? size - beginA : kBlockSize;  // first half is never smaller than the second
       }
-      words = encodeRows<P, FT, false, kSpill>(src, n, divUp(nA, 32u), sTable, tableLds, stageLds, dummyLds,
+      words = encodeRows<P, FT, false, kSpill, kEntry8>(src, n, divUp(nA, 32u), sTable, tableLds, stageLds, dummyLds,
                                                nullptr, hl, upper, spillSlot, spilled, state);
     }
 

@@ -1232,3 +1232,131 @@ def test_large_single_element(dg):
     dec = dg.decompress_data_simple(True, comp)
     assert torch.equal(dec[0].view(torch.int16), t.view(torch.int16))
     assert comp[0].numel() < n * 2
+
+
+# ---------------------------------------------------------------------------
+# k_ans_decode_mt (raw bytes, elements of more than 8 blocks): four blocks per wavefront, 1 KiB word rings with
+# 128-word chunks refilled every four rows, element slices per workgroup.
+def _mt_block(rng, kind):
+    if kind == "z":   # one symbol only: pdf = 2^P, the block emits no words at all
+        return np.full(4096, 7, np.uint8)
+    if kind == "c":   # ~1.2 bits per symbol: ~310 words, within the first three chunks
+        return rng.choice(np.array([7, 1, 2, 3], np.uint8), 4096, p=[0.7, 0.2, 0.07, 0.03])
+    if kind == "m":   # ~5 bits per symbol (Zipf-like): ~1300 words, ring in steady state
+        return (rng.zipf(1.3, 4096) % 256).astype(np.uint8)
+    return rng.integers(0, 256, 4096, dtype=np.uint8)  # "r": incompressible, up to 32 words per row
+
+
+@pytest.mark.parametrize("prob_bits", [9, 10, 11])
+def test_decode_mt_block_mixes(dg, prob_bits):
+    # every combination of block kinds inside a quad, quads that mix full and partial blocks, element tails of
+    # 1 / 2 / 3 blocks + a partial block, an element of exactly 9 blocks (two full quads + one block)
+    rng = np.random.default_rng(777 + prob_bits)
+    pats = ["zcmr" * 8 + "rrrr" + "zzzz" + "cccc", "rzrz" * 5 + "mmc", "m" * 9, "crmz" * 4 + "rr", "r" * 37, "zm" * 6 + "z"]
+    tails = [0, 1, 4095, 33, 2049, 0]
+    xs = []
+    for p, t in zip(pats, tails):
+        parts = [_mt_block(rng, k) for k in p]
+        if t:
+            parts.append(rng.integers(0, 256, t, dtype=np.uint8))
+        xs.append(np.concatenate(parts))
+    got = gpu_ans_encode(dg, xs, prob_bits)
+    for x, g in zip(xs, got):
+        want = O.ans_encode(x, prob_bits)
+        assert g.size == want.size and (g == want).all()
+    outs, status, osz = gpu_ans_decode(dg, got, [x.size for x in xs], prob_bits)
+    assert status.all() and osz.tolist() == [x.size for x in xs]
+    for i, (x, o) in enumerate(zip(xs, outs)):
+        assert (o == x).all(), (i, int(np.flatnonzero(o != x)[0]))
+
+
+def test_decode_mt_chunk_boundaries(dg):
+    # blocks whose compressed word counts sit on both sides of every chunk boundary of the 1 KiB ring protocol
+    # (128-word chunks: 127 .. 129, 255 .. 257, 383 .. 385, 511 .. 513, ...), found by searching symbol mixes
+    rng = np.random.default_rng(31337)
+    targets = set()
+    for k in range(1, 12):
+        targets.update({128 * k - 1, 128 * k, 128 * k + 1})
+    found = {}
+    base = rng.integers(0, 256, 4096, dtype=np.uint8)
+    # the table comes from the whole element, so word counts are steered by how many positions of a block hold
+    # the (frequent) filler symbol: sweep that count and keep blocks that land on a target
+    blocks = []
+    for fill in range(0, 4097, 8):
+        blk = base.copy()
+        blk[rng.permutation(4096)[:fill]] = 0
+        blocks.append(blk)
+    filler = np.zeros(4096 * 24, np.uint8)
+    x = np.concatenate(blocks + [filler])
+    arch = O.ans_encode(x, 10)
+    words = _block_words(arch)[: len(blocks)]
+    hit = sorted(set(int(w) for w in words) & targets)
+    assert len(hit) >= 6, hit  # the sweep is dense enough to land on several boundaries
+    got = gpu_ans_encode(dg, [x], 10)[0]
+    assert got.size == arch.size and (got == arch).all()
+    outs, status, _ = gpu_ans_decode(dg, [got], [x.size], 10)
+    assert status.all() and (outs[0] == x).all()
+
+
+def test_decode_mt_slices_and_batches(dg):
+    # ragged batch: elements of 9 .. 300 blocks next to tiny ones (the grid is laid out for the largest capacity;
+    # slices beyond an element's end and whole absent slices must do nothing), capacity larger than the size
+    rng = np.random.default_rng(2024)
+    sizes = [4096 * 300 + 17, 4096 * 9, 5, 4096 * 64, 0, 4096 * 131 + 4000, 4096 * 33 - 1]
+    xs = [(rng.zipf(1.25, n) % 256).astype(np.uint8) for n in sizes]
+    got = gpu_ans_encode(dg, xs, 10)
+    for x, g in zip(xs, got):
+        want = O.ans_encode(x, 10)
+        assert g.size == want.size and (g == want).all()
+    outs, status, osz = gpu_ans_decode(dg, got, [n + 100 for n in sizes], 10)
+    assert status.all() and osz.tolist() == sizes
+    for x, o in zip(xs, outs):
+        assert (o[: x.size] == x).all()
+
+
+def test_decode_mt_rejects_malformed_archives(dg):
+    # the checks of test_decoder_rejects_malformed_ans_archives on an element large enough for k_ans_decode_mt
+    # (40 blocks: two slices' worth of quads), corruptions in the middle of the block table included
+    x = refgen.generate_symbols(39 * 4096 + 100, 20.0)
+    good = O.ans_encode(x, 10)
+    ref = torch.from_numpy(x).to(DEV)
+    st, out = _decode_status(dg, False, good, ref)
+    assert st == 1 and torch.equal(out, ref)
+    nb = 40
+    bw0 = 32 + 512 + 128 * nb
+
+    def u32(a, off):
+        return a[off : off + 4].view(np.uint32)
+
+    cases = []
+    for name, off, val in [
+        ("numBlocks+1", 4, nb + 1), ("total-1", 8, x.size - 1), ("probBits", 16, 9), ("totalCompressedWords small", 12, 64),
+        ("block17 uncompressed size", bw0 + 17 * 8, (4095 << 16) | int(u32(good, bw0 + 17 * 8)[0] & 0xffff)),
+        ("block22 start past the end", bw0 + 22 * 8 + 4, int(u32(good, 12)[0])),
+        ("block35 start unaligned", bw0 + 35 * 8 + 4, int(u32(good, bw0 + 35 * 8 + 4)[0]) + 5),
+        ("last block size", bw0 + 39 * 8, (101 << 16) | int(u32(good, bw0 + 39 * 8)[0] & 0xffff)),
+    ]:
+        bad = good.copy()
+        u32(bad, off)[0] = val
+        cases.append((name, bad))
+    bad = good.copy()
+    bad[32:34].view(np.uint16)[0] += 1
+    cases.append(("pdf sum", bad))
+    for name, bad in cases:
+        st, _ = _decode_status(dg, False, bad, ref)
+        assert st == 0, name
+    # garbage lane states keep every invariant the decoder checks: it decodes garbage without faulting and writes
+    # nothing past the capacity
+    guard = torch.full((x.size + 8192,), 0xAB, dtype=torch.uint8, device=DEV)
+    rng = np.random.default_rng(5)
+    bad = good.copy()
+    st_off = 32 + 512
+    bad[st_off : st_off + 128 * nb] = rng.integers(0, 256, 128 * nb, dtype=np.uint8)
+    status = torch.zeros((1,), dtype=torch.uint8, device=DEV)
+    dg.decompress_data(False, [torch.from_numpy(bad).to(DEV)], [guard[: x.size]], False, None, status, None)
+    torch.cuda.synchronize()
+    assert (guard[x.size :] == 0xAB).all()
+    # truncated (the tensor API bounds the archive)
+    for cut in (32, 544, bw0 + 8, good.size - 16):
+        st, _ = _decode_status(dg, False, good[:cut], ref)
+        assert st == 0, cut
