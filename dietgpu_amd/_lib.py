@@ -14,6 +14,7 @@ u32, i32, sz, vp = C.c_uint32, C.c_int, C.c_size_t, C.c_void_p
 _SIGS = {
     "dgpu_version": (C.c_char_p, []),
     "dgpu_last_error": (C.c_char_p, []),
+    "dgpu_last_checksum_mismatches": (C.c_uint32, [C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32]),
     "dgpu_ans_max_compressed_size": (u32, [u32]),
     "dgpu_float_max_compressed_size": (u32, [u32, u32]),
     "dgpu_ans_encode_temp_bytes": (sz, [u32, u32]),

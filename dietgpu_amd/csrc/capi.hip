@@ -29,6 +29,12 @@ using namespace dgpu;
 namespace {
 
 thread_local std::string g_lastError;
+// every batch member whose checksum did not match in this thread's last decode call (GpuANSDecode.cuh:581-590)
+struct ChecksumMismatch {
+  int32_t batch;
+  uint32_t expected, got;
+};
+thread_local std::vector<ChecksumMismatch> g_mismatches;
 
 int fail(int code, const std::string& msg) {
   g_lastError = msg;
@@ -1277,6 +1283,7 @@ int decodeImpl(
   DGPU_REQUIRE(B <= 65535u, "numInBatch must be <= 65535");
   if (tempUsed) *tempUsed = 0;
   if (errBatch) *errBatch = -1;
+  g_mismatches.clear();
   if (B == 0) return DGPU_OK;
 
   StreamLease streamLease(stream);
@@ -1361,18 +1368,22 @@ int decodeImpl(
     DGPU_HIP(hipMemcpyAsync(h.data(), sums, h.size() * 4, hipMemcpyDeviceToHost, stream));
     DGPU_HIP(hipMemcpyAsync(ok.data(), successForChecksum, B, hipMemcpyDeviceToHost, stream));
     DGPU_HIP(hipStreamSynchronize(stream));
+    // EVERY mismatching member is reported, as upstream pushes every one into errorInfo; the message is the
+    // reference's, one line per member (its stringstream is never reset, so the text accumulates)
+    std::string msg;
     for (uint32_t i = 0; i < B; ++i) {
       if (ok[i] && h[i] != h[B + i]) {
         char buf[160];
         snprintf(buf, sizeof(buf),
-                 "Checksum mismatch in batch member %u: expected checksum %x got %x", i,
+                 "Checksum mismatch in batch member %u: expected checksum %x got %x\n", i,
                  h[B + i], h[i]);
-        g_lastError = buf;
-        if (errBatch) *errBatch = (int32_t)i;
+        msg += buf;
+        g_mismatches.push_back({(int32_t)i, h[B + i], h[i]});
+        if (status == DGPU_OK && errBatch) *errBatch = (int32_t)i;
         status = DGPU_ERR_CHECKSUM_MISMATCH;
-        break;
       }
     }
+    if (status != DGPU_OK) g_lastError = msg;
   }
   if (tempUsed) *tempUsed = arena.requested();
   return status;
@@ -1404,6 +1415,16 @@ extern "C" {
 
 const char* dgpu_version(void) { return "dietgpu_amd 0.1 (gfx950)"; }
 const char* dgpu_last_error(void) { return g_lastError.c_str(); }
+
+uint32_t dgpu_last_checksum_mismatches(int32_t* batchIdx, uint32_t* expected, uint32_t* got, uint32_t cap) {
+  const uint32_t n = (uint32_t)g_mismatches.size();
+  for (uint32_t i = 0; i < n && i < cap; ++i) {
+    if (batchIdx) batchIdx[i] = g_mismatches[i].batch;
+    if (expected) expected[i] = g_mismatches[i].expected;
+    if (got) got[i] = g_mismatches[i].got;
+  }
+  return n;
+}
 
 #ifdef DGPU_PHASE_TIMING
 // debug builds only: point the encode kernel's phase-timing hook at a device buffer

@@ -59,8 +59,9 @@ std::tuple<int64_t, int64_t> totalAndMaxSize(const std::vector<at::Tensor>& ts) 
 void* streamOf(int dev) { return (void*)c10::hip::getCurrentHIPStream(dev).stream(); }
 
 void check(int rc, const char* what, bool isFloat) {
+  // (DietGpu.cpp:626-633 / 801-808 raise this text; the members are what upstream's errorInfo lists)
   TORCH_CHECK(rc != DGPU_ERR_CHECKSUM_MISMATCH, isFloat ? "floatDecompress" : "ANSDecode",
-              ": checksum mismatch seen on decoded data; archive cannot be unpacked");
+              ": checksum mismatch seen on decoded data; archive cannot be unpacked\n", dgpu_last_error());
   TORCH_CHECK(rc == DGPU_OK, what, " failed: ", dgpu_last_error());
 }
 

@@ -228,7 +228,8 @@ def _raise_checksum(rc, is_float):
     if rc == 3:  # DGPU_ERR_CHECKSUM_MISMATCH
         raise RuntimeError(
             ("floatDecompress" if is_float else "ANSDecode")
-            + ": checksum mismatch seen on decoded data; archive cannot be unpacked")
+            + ": checksum mismatch seen on decoded data; archive cannot be unpacked\n"
+            + lib().dgpu_last_error().decode())
     check(rc)
 
 

@@ -29,8 +29,11 @@
  *
  * Return value: 0 on success, a DGPU_ERR_* code otherwise.  Decode calls
  * additionally report a checksum mismatch as DGPU_ERR_CHECKSUM_MISMATCH with
- * the first failing batch index in `*errBatch` (ANSDecodeStatus /
- * FloatDecompressStatus, GpuANSCodec.h:45-59, GpuFloatCodec.h:84-99).
+ * the first failing batch index in `*errBatch`; EVERY failing member (upstream
+ * pushes each one into `errorInfo`, GpuANSDecode.cuh:581-590,
+ * GpuFloatDecompress.cuh:720-733) is available from
+ * dgpu_last_checksum_mismatches() (ANSDecodeStatus / FloatDecompressStatus,
+ * GpuANSCodec.h:45-59, GpuFloatCodec.h:84-99).
  */
 #ifndef DIETGPU_AMD_H
 #define DIETGPU_AMD_H
@@ -61,6 +64,12 @@ const char* dgpu_version(void);
 /* Text of the last error on the calling thread (HIP error string, failed
  * precondition).  The reference aborts through glog CHECK instead. */
 const char* dgpu_last_error(void);
+
+/* The batch members whose checksum did not match in the LAST decode call the calling thread made (thread-local,
+ * like dgpu_last_error): returns their number and writes up to `cap` of them, ascending batch index, into the
+ * arrays that are not NULL.  Replaces the `errorInfo` vector of ANSDecodeStatus / FloatDecompressStatus
+ * (GpuANSDecode.cuh:581-590, GpuFloatDecompress.cuh:720-733), which lists every mismatching member. */
+uint32_t dgpu_last_checksum_mismatches(int32_t* batchIdx, uint32_t* expected, uint32_t* got, uint32_t cap);
 
 /* ---- size queries -------------------------------------------------------- */
 /* getMaxCompressedSize, GpuANSCodec.h:22 / GpuANSEncode.cu:13-25 */

@@ -48,7 +48,20 @@ inline ANSDecodeStatus toStatus(int rc, int32_t errBatch) {
   ANSDecodeStatus s;
   if (rc == DGPU_ERR_CHECKSUM_MISMATCH) {
     s.error = ANSDecodeError::ChecksumMismatch;
-    s.errorInfo.emplace_back((int)errBatch, std::string(dgpu_last_error()));
+    // every mismatching member, each with the text accumulated so far -- upstream's stringstream is never reset
+    // (GpuANSDecode.cuh:579-590)
+    (void)errBatch;
+    const uint32_t n = dgpu_last_checksum_mismatches(nullptr, nullptr, nullptr, 0);
+    std::vector<int32_t> idx(n);
+    std::vector<uint32_t> want(n), got(n);
+    dgpu_last_checksum_mismatches(idx.data(), want.data(), got.data(), n);
+    std::string text;
+    for (uint32_t i = 0; i < n; ++i) {
+      char buf[160];
+      snprintf(buf, sizeof(buf), "Checksum mismatch in batch member %d: expected checksum %x got %x\n", (int)idx[i], want[i], got[i]);
+      text += buf;
+      s.errorInfo.emplace_back((int)idx[i], text);
+    }
   }
   return s;
 }

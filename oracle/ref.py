@@ -67,9 +67,21 @@ def lib():
         L.dgref_ans_decode_batch.restype = i32
         L.dgref_ans_decode_batch.argtypes = [i32, i32, u32, vp, vp, vp, vp, vp]
         L.dgref_float_compress_batch.restype = None
-        L.dgref_float_compress_batch.argtypes = [u32, i32, i32, u32, vp, vp, vp, vp]
+        L.dgref_float_compress_batch.argtypes = [u32, i32, i32, i32, u32, vp, vp, vp, vp]
         L.dgref_float_decompress_batch.restype = i32
-        L.dgref_float_decompress_batch.argtypes = [u32, i32, i32, u32, vp, vp, vp, vp, vp]
+        L.dgref_float_decompress_batch.argtypes = [u32, i32, i32, i32, u32, vp, vp, vp, vp, vp]
+        L.dgref_ans_encode_batch_stride.restype = None
+        L.dgref_ans_encode_batch_stride.argtypes = [i32, i32, u32, vp, u32, u32, vp, u32, vp]
+        L.dgref_ans_decode_batch_stride.restype = i32
+        L.dgref_ans_decode_batch_stride.argtypes = [i32, i32, u32, vp, u32, vp, u32, u32, vp, vp]
+        L.dgref_ans_encode_batch_split_size.restype = None
+        L.dgref_ans_encode_batch_split_size.argtypes = [i32, i32, u32, vp, vp, vp, u32, vp]
+        L.dgref_ans_decode_batch_split_size.restype = i32
+        L.dgref_ans_decode_batch_split_size.argtypes = [i32, i32, u32, vp, vp, vp, vp, vp]
+        L.dgref_float_compress_split_size.restype = None
+        L.dgref_float_compress_split_size.argtypes = [u32, i32, i32, i32, u32, vp, vp, vp, u32, vp]
+        L.dgref_float_decompress_split_size.restype = i32
+        L.dgref_float_decompress_split_size.argtypes = [u32, i32, i32, i32, u32, vp, vp, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -138,7 +150,9 @@ def ans_decode_batch(archives, capacities, prob_bits=10, use_checksum=False):
     return [o[:c].copy() for o, c in zip(outs, capacities)], ok, osz, rc
 
 
-def float_compress_batch(ft, rows, prob_bits=10, use_checksum=False):
+def float_compress_batch(ft, rows, prob_bits=10, use_checksum=False, aligned16=False):
+    """aligned16: FloatCodecConfig::is16ByteAligned (every buffer here IS 16-byte aligned): the reference's
+    vectorised split path (SplitFloatAligned16, GpuFloatCompress.cuh:85-278)."""
     L = lib()
     wb = np.dtype(_WORD[ft]).itemsize
     ins = []
@@ -150,12 +164,13 @@ def float_compress_batch(ft, rows, prob_bits=10, use_checksum=False):
     sizes = (C.c_uint32 * len(rows))(*[len(r) for r in rows])
     outs = [_aligned(int(L.dgref_float_max_compressed_size(ft, len(r)))) for r in rows]
     out_sizes = np.zeros(len(rows), np.uint32)
-    L.dgref_float_compress_batch(ft, prob_bits, int(use_checksum), len(rows), _ptrs(ins), sizes, _ptrs(outs),
+    L.dgref_float_compress_batch(ft, prob_bits, int(use_checksum), int(aligned16), len(rows), _ptrs(ins), sizes, _ptrs(outs),
                                  out_sizes.ctypes.data_as(C.c_void_p))
     return [o[:n].copy() for o, n in zip(outs, out_sizes)]
 
 
-def float_decompress_batch(ft, archives, capacities, prob_bits=10, use_checksum=False):
+def float_decompress_batch(ft, archives, capacities, prob_bits=10, use_checksum=False, aligned16=False):
+    """aligned16: the reference's JoinFloatAligned16 path (GpuFloatDecompress.cuh:25-270)."""
     L = lib()
     wb = np.dtype(_WORD[ft]).itemsize
     ins = []
@@ -167,7 +182,7 @@ def float_decompress_batch(ft, archives, capacities, prob_bits=10, use_checksum=
     caps = (C.c_uint32 * len(archives))(*capacities)
     ok = np.zeros(len(archives), np.uint8)
     osz = np.zeros(len(archives), np.uint32)
-    rc = L.dgref_float_decompress_batch(ft, prob_bits, int(use_checksum), len(archives), _ptrs(ins), _ptrs(outs), caps,
+    rc = L.dgref_float_decompress_batch(ft, prob_bits, int(use_checksum), int(aligned16), len(archives), _ptrs(ins), _ptrs(outs), caps,
                                         ok.ctypes.data_as(C.c_void_p), osz.ctypes.data_as(C.c_void_p))
     return [o[: c * wb].view(_WORD[ft]).copy() for o, c in zip(outs, capacities)], ok, osz, rc
 
@@ -181,3 +196,117 @@ def ans_header_fields(archive):
             "use_checksum", "checksum", "pdf_offset", "states_offset", "block_words_offset", "block_data_offset",
             "total_compressed_size")
     return dict(zip(keys, (int(v) for v in out)))
+
+
+# ---- the reference's other batch providers (stride, split size) ---------------------------------------------
+def ans_encode_batch_stride(matrix, prob_bits=10, use_checksum=False, in_stride=None):
+    """[B][n] uint8 -> list of archives through ansEncodeBatchStride (rows `in_stride` bytes apart)."""
+    L = lib()
+    b, n = matrix.shape
+    in_stride = in_stride or n
+    buf = _aligned(b * in_stride + 16)
+    for i in range(b):
+        buf[i * in_stride : i * in_stride + n] = matrix[i]
+    out_stride = int(L.dgref_ans_max_compressed_size(n))
+    out = _aligned(b * out_stride)
+    sizes = np.zeros(b, np.uint32)
+    L.dgref_ans_encode_batch_stride(prob_bits, int(use_checksum), b, C.c_void_p(buf.ctypes.data), n, in_stride,
+                                    C.c_void_p(out.ctypes.data), out_stride, sizes.ctypes.data_as(C.c_void_p))
+    return [out[i * out_stride : i * out_stride + sizes[i]].copy() for i in range(b)]
+
+
+def ans_decode_batch_stride(archives, n, prob_bits=10, use_checksum=False):
+    L = lib()
+    b = len(archives)
+    in_stride = (max(len(a) for a in archives) + 15) // 16 * 16
+    buf = _aligned(b * in_stride)
+    for i, a in enumerate(archives):
+        buf[i * in_stride : i * in_stride + len(a)] = a
+    out = _aligned(b * n, 0xCD)
+    ok = np.zeros(b, np.uint8)
+    osz = np.zeros(b, np.uint32)
+    rc = L.dgref_ans_decode_batch_stride(prob_bits, int(use_checksum), b, C.c_void_p(buf.ctypes.data), in_stride,
+                                         C.c_void_p(out.ctypes.data), n, n, ok.ctypes.data_as(C.c_void_p),
+                                         osz.ctypes.data_as(C.c_void_p))
+    return out.reshape(b, n).copy(), ok, osz, rc
+
+
+def ans_encode_batch_split_size(rows, prob_bits=10, use_checksum=False):
+    """rows back to back in ONE buffer (BatchProviderSplitSize) -> list of archives."""
+    L = lib()
+    sizes_in = [len(r) for r in rows]
+    buf = _aligned(sum(sizes_in) + 16)
+    pos = 0
+    for r in rows:
+        buf[pos : pos + len(r)] = r
+        pos += len(r)
+    out_stride = int(L.dgref_ans_max_compressed_size(max(sizes_in)))
+    out = _aligned(len(rows) * out_stride)
+    split = (C.c_uint32 * len(rows))(*sizes_in)
+    sizes = np.zeros(len(rows), np.uint32)
+    L.dgref_ans_encode_batch_split_size(prob_bits, int(use_checksum), len(rows), C.c_void_p(buf.ctypes.data), split,
+                                        C.c_void_p(out.ctypes.data), out_stride, sizes.ctypes.data_as(C.c_void_p))
+    return [out[i * out_stride : i * out_stride + sizes[i]].copy() for i in range(len(rows))]
+
+
+def ans_decode_batch_split_size(archives, sizes_out, prob_bits=10, use_checksum=False):
+    L = lib()
+    ins = []
+    for a in archives:
+        b = _aligned(len(a))
+        b[:] = a
+        ins.append(b)
+    out = _aligned(sum(sizes_out) + 16, 0xCD)
+    split = (C.c_uint32 * len(archives))(*sizes_out)
+    ok = np.zeros(len(archives), np.uint8)
+    osz = np.zeros(len(archives), np.uint32)
+    rc = L.dgref_ans_decode_batch_split_size(prob_bits, int(use_checksum), len(archives), _ptrs(ins),
+                                             C.c_void_p(out.ctypes.data), split, ok.ctypes.data_as(C.c_void_p),
+                                             osz.ctypes.data_as(C.c_void_p))
+    outs, pos = [], 0
+    for n in sizes_out:
+        outs.append(out[pos : pos + n].copy())
+        pos += n
+    return outs, ok, osz, rc
+
+
+def float_compress_split_size(ft, rows, prob_bits=10, use_checksum=False, aligned16=False):
+    L = lib()
+    wb = np.dtype(_WORD[ft]).itemsize
+    sizes_in = [len(r) for r in rows]
+    buf = _aligned(sum(sizes_in) * wb + 16)
+    pos = 0
+    for r in rows:
+        r = np.ascontiguousarray(r, _WORD[ft])
+        buf[pos : pos + r.size * wb] = r.view(np.uint8)
+        pos += r.size * wb
+    out_stride = int(L.dgref_float_max_compressed_size(ft, max(sizes_in)))
+    out = _aligned(len(rows) * out_stride)
+    split = (C.c_uint32 * len(rows))(*sizes_in)
+    sizes = np.zeros(len(rows), np.uint32)
+    L.dgref_float_compress_split_size(ft, prob_bits, int(use_checksum), int(aligned16), len(rows),
+                                      C.c_void_p(buf.ctypes.data), split, C.c_void_p(out.ctypes.data), out_stride,
+                                      sizes.ctypes.data_as(C.c_void_p))
+    return [out[i * out_stride : i * out_stride + sizes[i]].copy() for i in range(len(rows))]
+
+
+def float_decompress_split_size(ft, archives, sizes_out, prob_bits=10, use_checksum=False, aligned16=False):
+    L = lib()
+    wb = np.dtype(_WORD[ft]).itemsize
+    ins = []
+    for a in archives:
+        b = _aligned(len(a))
+        b[:] = a
+        ins.append(b)
+    out = _aligned(sum(sizes_out) * wb + 16, 0xCD)
+    split = (C.c_uint32 * len(archives))(*sizes_out)
+    ok = np.zeros(len(archives), np.uint8)
+    osz = np.zeros(len(archives), np.uint32)
+    rc = L.dgref_float_decompress_split_size(ft, prob_bits, int(use_checksum), int(aligned16), len(archives), _ptrs(ins),
+                                             C.c_void_p(out.ctypes.data), split, ok.ctypes.data_as(C.c_void_p),
+                                             osz.ctypes.data_as(C.c_void_p))
+    outs, pos = [], 0
+    for n in sizes_out:
+        outs.append(out[pos * wb : (pos + n) * wb].view(_WORD[ft]).copy())
+        pos += n
+    return outs, ok, osz, rc

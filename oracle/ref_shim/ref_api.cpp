@@ -110,17 +110,73 @@ int dgref_ans_decode_batch(int probBits, int useChecksum, uint32_t num, const vo
   if (st.error == ANSDecodeError::ChecksumMismatch) return 1 + (st.errorInfo.empty() ? 0 : st.errorInfo[0].first);
   return 0;
 }
-void dgref_float_compress_batch(uint32_t ft, int probBits, int useChecksum, uint32_t num, const void* const* in,
-                                const uint32_t* inSize, void* const* out, uint32_t* outSize) {
-  FloatCodecConfig cfg((FloatType)ft, ANSCodecConfig(probBits, false), false /* is16ByteAligned */, useChecksum != 0);
+// `aligned16`: FloatCodecConfig::is16ByteAligned -- what DietGpu.cpp passes for 16-byte aligned tensors; it selects
+// the reference's vectorised SplitFloatAligned16 / JoinFloatAligned16 paths (GpuFloatCompress.cuh:85-278,
+// GpuFloatDecompress.cuh:25-270).  The caller guarantees the alignment of every in / out pointer then.
+void dgref_float_compress_batch(uint32_t ft, int probBits, int useChecksum, int aligned16, uint32_t num,
+                                const void* const* in, const uint32_t* inSize, void* const* out, uint32_t* outSize) {
+  FloatCodecConfig cfg((FloatType)ft, ANSCodecConfig(probBits, false), aligned16 != 0, useChecksum != 0);
   StackDeviceMemory res(0, stackBytes(num, inSize, 4));
   floatCompress(res, cfg, num, (const void**)in, inSize, (void**)out, outSize, nullptr);
 }
-int dgref_float_decompress_batch(uint32_t ft, int probBits, int useChecksum, uint32_t num, const void* const* in,
-                                 void* const* out, const uint32_t* outCapacity, uint8_t* outSuccess, uint32_t* outSize) {
-  FloatCodecConfig cfg((FloatType)ft, ANSCodecConfig(probBits, false), false, useChecksum != 0);
+int dgref_float_decompress_batch(uint32_t ft, int probBits, int useChecksum, int aligned16, uint32_t num,
+                                 const void* const* in, void* const* out, const uint32_t* outCapacity,
+                                 uint8_t* outSuccess, uint32_t* outSize) {
+  FloatCodecConfig cfg((FloatType)ft, ANSCodecConfig(probBits, false), aligned16 != 0, useChecksum != 0);
   StackDeviceMemory res(0, stackBytes(num, outCapacity, 4));
   auto st = floatDecompress(res, cfg, num, (const void**)in, (void**)out, outCapacity, outSuccess, outSize, nullptr);
+  if (st.error == FloatDecompressError::ChecksumMismatch) return 1 + (st.errorInfo.empty() ? 0 : st.errorInfo[0].first);
+  return 0;
+}
+
+// ---- the other batch providers of the reference (BatchProvider.cuh:39-194) ------------------------------
+// ansEncodeBatchStride / ansDecodeBatchStride (GpuANSEncode.cu:27-53, GpuANSDecode.cu:20-45)
+void dgref_ans_encode_batch_stride(int probBits, int useChecksum, uint32_t num, const void* in, uint32_t inSize,
+                                   uint32_t inStride, void* out, uint32_t outStride, uint32_t* outSize) {
+  ANSCodecConfig cfg(probBits, useChecksum != 0);
+  std::vector<uint32_t> sizes(num, inSize);
+  StackDeviceMemory res(0, stackBytes(num, sizes.data(), 1));
+  ansEncodeBatchStride(res, cfg, num, in, inSize, inStride, nullptr, out, outStride, outSize, nullptr);
+}
+int dgref_ans_decode_batch_stride(int probBits, int useChecksum, uint32_t num, const void* in, uint32_t inStride,
+                                  void* out, uint32_t outStride, uint32_t outCapacity, uint8_t* outSuccess,
+                                  uint32_t* outSize) {
+  ANSCodecConfig cfg(probBits, useChecksum != 0);
+  std::vector<uint32_t> sizes(num, outCapacity);
+  StackDeviceMemory res(0, stackBytes(num, sizes.data(), 1));
+  auto st = ansDecodeBatchStride(res, cfg, num, in, inStride, out, outStride, outCapacity, outSuccess, outSize, nullptr);
+  if (st.error == ANSDecodeError::ChecksumMismatch) return 1 + (st.errorInfo.empty() ? 0 : st.errorInfo[0].first);
+  return 0;
+}
+// ansEncodeBatchSplitSize / ansDecodeBatchSplitSize (GpuANSEncode.cu:115-179, GpuANSDecode.cu:122-193)
+void dgref_ans_encode_batch_split_size(int probBits, int useChecksum, uint32_t num, const void* in,
+                                       const uint32_t* splitSizes, void* out, uint32_t outStride, uint32_t* outSize) {
+  ANSCodecConfig cfg(probBits, useChecksum != 0);
+  StackDeviceMemory res(0, stackBytes(num, splitSizes, 1));
+  ansEncodeBatchSplitSize(res, cfg, num, in, splitSizes, nullptr, out, outStride, outSize, nullptr);
+}
+int dgref_ans_decode_batch_split_size(int probBits, int useChecksum, uint32_t num, const void* const* in, void* out,
+                                      const uint32_t* splitSizes, uint8_t* outSuccess, uint32_t* outSize) {
+  ANSCodecConfig cfg(probBits, useChecksum != 0);
+  StackDeviceMemory res(0, stackBytes(num, splitSizes, 1));
+  auto st = ansDecodeBatchSplitSize(res, cfg, num, (const void**)in, out, splitSizes, outSuccess, outSize, nullptr);
+  if (st.error == ANSDecodeError::ChecksumMismatch) return 1 + (st.errorInfo.empty() ? 0 : st.errorInfo[0].first);
+  return 0;
+}
+// floatCompressSplitSize / floatDecompressSplitSize (GpuFloatCompress.cu:103-159, GpuFloatDecompress.cu:117-179)
+void dgref_float_compress_split_size(uint32_t ft, int probBits, int useChecksum, int aligned16, uint32_t num,
+                                     const void* in, const uint32_t* splitSizes, void* out, uint32_t outStride,
+                                     uint32_t* outSize) {
+  FloatCodecConfig cfg((FloatType)ft, ANSCodecConfig(probBits, false), aligned16 != 0, useChecksum != 0);
+  StackDeviceMemory res(0, stackBytes(num, splitSizes, 4));
+  floatCompressSplitSize(res, cfg, num, in, splitSizes, out, outStride, outSize, nullptr);
+}
+int dgref_float_decompress_split_size(uint32_t ft, int probBits, int useChecksum, int aligned16, uint32_t num,
+                                      const void* const* in, void* out, const uint32_t* splitSizes,
+                                      uint8_t* outSuccess, uint32_t* outSize) {
+  FloatCodecConfig cfg((FloatType)ft, ANSCodecConfig(probBits, false), aligned16 != 0, useChecksum != 0);
+  StackDeviceMemory res(0, stackBytes(num, splitSizes, 4));
+  auto st = floatDecompressSplitSize(res, cfg, num, (const void**)in, out, splitSizes, outSuccess, outSize, nullptr);
   if (st.error == FloatDecompressError::ChecksumMismatch) return 1 + (st.errorInfo.empty() ? 0 : st.errorInfo[0].first);
   return 0;
 }

@@ -86,6 +86,26 @@ int main() {
     EXPECT(tiny.getMaxMemoryUsage() > 1024);
   }
 
+  {
+    // checksum mismatch in TWO of the three members: errorInfo lists both (GpuANSDecode.cuh:581-590), each with
+    // the text accumulated so far, as upstream
+    for (int i : {0, 2}) {
+      uint32_t word;
+      HIP(hipMemcpy(&word, (char*)comp[i] + 20, 4, hipMemcpyDeviceToHost));  // ANSCoalescedHeader::checksum
+      word ^= 0x5a;
+      HIP(hipMemcpy((char*)comp[i] + 20, &word, 4, hipMemcpyHostToDevice));
+    }
+    auto bad = ansDecodeBatchPointer(res, cfg, 3, (const void**)comp.data(), out.data(), cap.data(), success_dev, decSize_dev, stream);
+    EXPECT(bad.error == ANSDecodeError::ChecksumMismatch);
+    EXPECT(bad.errorInfo.size() == 2);
+    if (bad.errorInfo.size() == 2) {
+      EXPECT(bad.errorInfo[0].first == 0 && bad.errorInfo[1].first == 2);
+      EXPECT(bad.errorInfo[0].second.find("batch member 0") != std::string::npos);
+      EXPECT(bad.errorInfo[1].second.find("batch member 0") != std::string::npos &&
+             bad.errorInfo[1].second.find("batch member 2") != std::string::npos);
+    }
+  }
+
   // --- float codec, bf16, batch of 2 (FloatTest.cu: Batch) ---
   std::normal_distribution<float> nd;
   std::vector<uint32_t> fsizes = {8192 + 5, 30000};

@@ -6,8 +6,14 @@ comparisons with archives produced by the reference itself blank them first.
               touch bits 0..4 of an uninitialised word, :134-147), `checksum` when the checksum is off
               (GpuANSEncode.cuh:557-559), `unused0`, `unused1`.
   Float header (GpuFloatUtils.cuh:61-72): options bits 5..31, `checksum` when off.
-Everything else -- pdf table, warp states, block table, block data and their padding, non-compressed
-planes -- is compared as is (oracle/_ref runs the reference on zero-filled memory).
+  Block padding (GpuANSEncode.cuh:618-627): the coalesce kernel copies roundUp(words, 8) words of every block out
+              of the per-block scratch buffer, i.e. up to 7 words the encoder never wrote.  oracle/_ref runs the
+              reference on zero-filled memory, so they are zero as long as the scratch region was not used for
+              something else earlier in the same call; in large batches the reference's temp stack hands the
+              encoder memory an earlier temporary has written (first seen: row 0 of an 8 x 1 MiB batch, word
+              1358 of block 0), so the pad words are blanked too.
+Everything else -- pdf table, warp states, block table, the blocks' own words, non-compressed planes -- is compared
+as is.
 """
 import numpy as np
 
@@ -27,6 +33,18 @@ def mask_ans(a, off=0):
     if not use_ck:
         a[off + 20 : off + 24] = 0
     a[off + 24 : off + 32] = 0
+    # pad words of every block
+    nb = int.from_bytes(a[off + 4 : off + 8].tobytes(), "little")
+    table = off + 32 + 512 + 128 * nb
+    data = table + 8 * ((nb + 1) // 2 * 2)
+    if nb and data <= a.size:
+        bw = a[table : table + 8 * nb].view(np.uint32).reshape(nb, 2)
+        words = (bw[:, 0] & 0xFFFF).astype(np.int64)
+        start = bw[:, 1].astype(np.int64)
+        for w, st in zip(words, start):
+            lo, hi = data + 2 * (st + w), data + 2 * (st + (w + 7) // 8 * 8)
+            if hi <= a.size:
+                a[lo:hi] = 0
     return a
 
 

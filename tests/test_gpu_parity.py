@@ -1360,3 +1360,49 @@ def test_decode_mt_rejects_malformed_archives(dg):
     for cut in (32, 544, bw0 + 8, good.size - 16):
         st, _ = _decode_status(dg, False, good[:cut], ref)
         assert st == 0, cut
+
+
+@pytest.mark.parametrize("as_float", [False, True])
+def test_checksum_mismatch_reports_every_member(dg, as_float):
+    # upstream pushes EVERY mismatching batch member into errorInfo (GpuANSDecode.cuh:581-590,
+    # GpuFloatDecompress.cuh:720-733): three corrupted members of a batch of ten, through the tensor API message
+    # and through the C ABI's dgpu_last_checksum_mismatches
+    rng = np.random.default_rng(8)
+    if as_float:
+        words = [refgen.generate_floats(O.BFLOAT16, 5000 + 37 * i) for i in range(10)]
+        ts = [words_to_tensor(O.BFLOAT16, w) for w in words]
+        ck_off = 12  # GpuFloatHeader::checksum
+    else:
+        ts = [to_dev_bytes(rng.integers(0, 50, 9000 + 11 * i, dtype=np.uint8)) for i in range(10)]
+        ck_off = 20  # ANSCoalescedHeader::checksum
+    comp, sizes, _ = dg.compress_data(as_float, ts, True)
+    sizes = sizes.cpu().numpy()
+    rows = [comp[i, : sizes[i]].clone() for i in range(10)]
+    for i in (1, 4, 9):
+        rows[i][ck_off] ^= 0x3C
+    outs = [torch.empty_like(t) for t in ts]
+    with pytest.raises(RuntimeError, match="checksum mismatch") as ei:
+        dg.decompress_data(as_float, rows, outs, True)
+    text = str(ei.value)
+    for i in (1, 4, 9):
+        assert f"batch member {i}:" in text
+    for i in (0, 2, 3, 5, 6, 7, 8):
+        assert f"batch member {i}:" not in text
+    L = dg.lib()
+    idx = (C.c_int32 * 16)()
+    want = (C.c_uint32 * 16)()
+    got = (C.c_uint32 * 16)()
+    n = L.dgpu_last_checksum_mismatches(idx, want, got, 16)
+    assert n == 3 and list(idx[:3]) == [1, 4, 9]
+    assert all(want[k] == (got[k] ^ 0x3C) for k in range(3))
+    assert L.dgpu_last_checksum_mismatches(None, None, None, 0) == 3  # count only
+    # a clean call resets the list
+    rows2 = [comp[i, : sizes[i]] for i in range(10)]
+    dg.decompress_data(as_float, rows2, outs, True)
+    assert L.dgpu_last_checksum_mismatches(None, None, None, 0) == 0
+    # the fast tensor surface raises the same text
+    import dietgpu_amd
+
+    dietgpu_amd.load_torch_ops()
+    with pytest.raises(RuntimeError, match="batch member 4:"):
+        torch.ops.dietgpu.decompress_data(as_float, rows, outs, True, None, None, None)

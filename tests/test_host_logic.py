@@ -40,3 +40,19 @@ def test_bench_checks_world_size_against_flag():
     assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
     p = _bench(["--gpus", "0"], {})
     assert p.returncode != 0
+
+
+def test_collection_from_the_repo_root_needs_no_gpu():
+    """`pytest --collect-only` from the repo root (no path argument) must succeed on a CPU box: nothing outside
+    tests/ may look like a test module, and no test module may touch the GPU at import."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-m", "pytest", "--collect-only", "-q", "-p", "no:cacheprovider"],
+                       cwd=root, capture_output=True, text=True, timeout=600,
+                       env={**os.environ, "HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": ""})
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "error" not in p.stdout.lower().split("\n")[-2], p.stdout[-500:]
+    # and nothing under tools/ (experiment scripts that do GPU work at import) is collected
+    assert "tools/" not in p.stdout

@@ -173,3 +173,85 @@ def test_baseline_config_rows():
     assert same(R.float_compress_batch(O.BFLOAT16, [w], 10)[0], O.float_compress(O.BFLOAT16, w, 10), mask_float)
     h = refgen.sparse_fp16(1, 512 * 1024)[0]
     assert same(R.float_compress_batch(O.FLOAT16, [h], 11)[0], O.float_compress(O.FLOAT16, h, 11), mask_float)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Round 3: the reference paths the pin did not execute before ("Reference paths the pin never executes")
+@pytest.mark.parametrize("ft", [O.FLOAT16, O.BFLOAT16, O.FLOAT32])
+def test_float_aligned16_paths_of_the_reference(ft):
+    # is16ByteAligned = true selects SplitFloatAligned16 / JoinFloatAligned16 (GpuFloatCompress.cuh:85-278,
+    # GpuFloatDecompress.cuh:25-270) -- the path DietGpu.cpp takes for 16-byte aligned tensors.  Same archives as the
+    # unaligned path and as the oracle; the reference's aligned JOIN decodes oracle archives.
+    for n, p in ((4096 * 3 + 8, 10), (16, 9), (8 * 1000 + 8, 11), (4096 * 2 + 5, 10), (33, 10), (0, 10)):
+        w = refgen.generate_floats(ft, n)
+        ora = O.float_compress(ft, w, p)
+        a = R.float_compress_batch(ft, [w], p, False, aligned16=True)[0]
+        u = R.float_compress_batch(ft, [w], p, False, aligned16=False)[0]
+        assert same(a, ora, mask_float), (ft, n, p)
+        assert same(a, u, mask_float)
+        outs, ok, osz, rc = R.float_decompress_batch(ft, [ora], [n], p, False, aligned16=True)
+        assert ok[0] == 1 and osz[0] == n and rc == 0 and (outs[0] == w).all()
+    # with the checksum (its float quirk: the word count is used as a byte count) and in a batch
+    ws = [refgen.generate_floats(ft, n) for n in (4096 + 16, 8, 4096 * 5)]
+    refs = R.float_compress_batch(ft, ws, 10, True, aligned16=True)
+    for w, r in zip(ws, refs):
+        assert same(r, O.float_compress(ft, w, 10, use_checksum=True), mask_float)
+    outs, ok, osz, rc = R.float_decompress_batch(ft, refs, [w.size for w in ws], 10, True, aligned16=True)
+    assert rc == 0 and ok.all() and all((o == w).all() for o, w in zip(outs, ws))
+
+
+def test_two_level_prefix_sum_of_the_reference():
+    # more than 512 blocks per element: batchExclusivePrefixSum takes its two-level path
+    # (BatchPrefixSum.cuh:69-110).  One raw element of 3 MiB + 5 bytes (769 blocks) and one bf16 tensor of
+    # 2.6 M words (635 blocks of exponents), byte for byte.
+    x = refgen.generate_symbols(3 * (1 << 20) + 5, 40.0)
+    r = R.ans_encode_batch([x], 10)[0]
+    assert R.ans_header_fields(r)["num_blocks"] == 769
+    assert same(r, O.ans_encode(x, 10), mask_ans)
+    outs, ok, osz, rc = R.ans_decode_batch([O.ans_encode(x, 10)], [x.size], 10)
+    assert ok[0] == 1 and (outs[0] == x).all()
+    w = refgen.normal_bf16(1, 2_600_000)[0]
+    assert same(R.float_compress_batch(O.BFLOAT16, [w], 10, False, aligned16=True)[0], O.float_compress(O.BFLOAT16, w, 10), mask_float)
+
+
+def test_baseline_config_rows_eight_each():
+    # eight rows (not one) of each BASELINE config through the reference, full size, as ONE batch
+    xs = list(refgen.zipf_bytes(8, 1 << 20))
+    for x, r in zip(xs, R.ans_encode_batch(xs, 10)):
+        assert same(r, O.ans_encode(x, 10), mask_ans)
+    ws = list(refgen.normal_bf16(8, 512 * 1024))
+    for w, r in zip(ws, R.float_compress_batch(O.BFLOAT16, ws, 10, False, aligned16=True)):
+        assert same(r, O.float_compress(O.BFLOAT16, w, 10), mask_float)
+    hs = list(refgen.sparse_fp16(8, 512 * 1024))
+    for h, r in zip(hs, R.float_compress_batch(O.FLOAT16, hs, 11, False, aligned16=True)):
+        assert same(r, O.float_compress(O.FLOAT16, h, 11), mask_float)
+
+
+def test_stride_and_split_size_providers_of_the_reference():
+    # ansEncodeBatchStride / ansDecodeBatchStride (GpuANSEncode.cu:27-53, GpuANSDecode.cu:20-45) and
+    # ansEncodeBatchSplitSize / ansDecodeBatchSplitSize (GpuANSEncode.cu:115-179, GpuANSDecode.cu:122-193), and the
+    # float split-size pair (GpuFloatCompress.cu:103-159, GpuFloatDecompress.cu:117-179): the same archives as the
+    # pointer API and the oracle, and they decode
+    rng = np.random.default_rng(3)
+    m = np.stack([refgen.generate_symbols(4096 * 2 + 100, lam) for lam in (5.0, 20.0, 100.0)])
+    for stride in (None, 4096 * 3):
+        refs = R.ans_encode_batch_stride(m, 10, True, stride)
+        for row, r in zip(m, refs):
+            assert same(r, O.ans_encode(row, 10, use_checksum=True), mask_ans)
+    out, ok, osz, rc = R.ans_decode_batch_stride([O.ans_encode(row, 10, use_checksum=True) for row in m], m.shape[1], 10, True)
+    assert rc == 0 and ok.all() and (osz == m.shape[1]).all() and (out == m).all()
+
+    rows = [rng.integers(0, 30, n, dtype=np.uint8) for n in (4096 * 2, 100, 4096 + 4, 8)]  # 4-byte aligned starts
+    refs = R.ans_encode_batch_split_size(rows, 11)
+    for row, r in zip(rows, refs):
+        assert same(r, O.ans_encode(row, 11), mask_ans)
+    outs, ok, osz, rc = R.ans_decode_batch_split_size([O.ans_encode(r, 11) for r in rows], [len(r) for r in rows], 11)
+    assert rc == 0 and ok.all() and all((o == r).all() for o, r in zip(outs, rows))
+
+    for ft in (O.FLOAT16, O.BFLOAT16, O.FLOAT32):
+        ws = [refgen.generate_floats(ft, n) for n in (4096 + 8, 16, 4096 * 2)]
+        refs = R.float_compress_split_size(ft, ws, 10)
+        for w, r in zip(ws, refs):
+            assert same(r, O.float_compress(ft, w, 10), mask_float), ft
+        outs, ok, osz, rc = R.float_decompress_split_size(ft, [O.float_compress(ft, w, 10) for w in ws], [w.size for w in ws], 10)
+        assert rc == 0 and ok.all() and all((o == w).all() for o, w in zip(outs, ws))
