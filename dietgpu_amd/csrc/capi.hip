@@ -1209,17 +1209,18 @@ int floatCompressImpl(
   return rc;
 }
 
-// DGPU_DEC_MT: the four-blocks-per-wavefront decoder for raw bytes (kernels_decode_mt.h); environment DGPU_DEC_MT=0
-// switches back to k_ans_decode's 16-block tiles (A/B runs)
+// DGPU_DEC_MT: which decoder raw-byte elements of more than 8 blocks get (kernels_decode_mt.h): 0 = k_ans_decode's
+// 16-block tiles, 1 = two chains per wavefront on 1 KiB rings, 2 = one chain on 2 KiB rings, 3 = two chains on 2 KiB
+// rings with 4-wavefront workgroups; environment DGPU_DEC_MT overrides (A/B runs)
 #ifndef DGPU_DEC_MT
 #define DGPU_DEC_MT 1
 #endif
-bool decodeMtEnabled() {
-  static const bool on = [] {
+int decodeMtVariant() {
+  static const int v = [] {
     const char* e = getenv("DGPU_DEC_MT");
-    return e ? e[0] != '0' : (DGPU_DEC_MT != 0);
+    return e ? atoi(e) : (int)DGPU_DEC_MT;
   }();
-  return on;
+  return v;
 }
 
 template <int P, uint32_t FT>
@@ -1237,18 +1238,26 @@ int launchDecodePF(const DecodeArgs& a, uint32_t tileBlocks, dim3 grid, hipStrea
   } else if (tileBlocks == kDecBlocksPerSmallTile) {
     DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode<P, FT, kDecBlocksPerSmallTile>), grid, dim3(kDecBlocksPerSmallTile * 32u),
                 decLdsBytes(P, FT, kDecBlocksPerSmallTile), stream, a);
-  } else if (FT == 0 && decodeMtEnabled()) {
-    // raw bytes, elements of more than 8 blocks: four blocks per wavefront, two row chains (kernels_decode_mt.h).
-    // A workgroup takes a slice of an element: as many 32-block rounds as leaves every CU its four workgroups.
+  } else if (FT == 0 && decodeMtVariant() != 0) {
+    // raw bytes, elements of more than 8 blocks: several blocks per wavefront / scalar ring maintenance
+    // (kernels_decode_mt.h).  A workgroup takes a slice of an element: as many rounds as leaves every CU its
+    // share of workgroups.
     if constexpr (FT == 0) {
       const uint32_t maxBlocks = grid.x * kDecBlocksPerTile;
-      const uint32_t roundsPerElem = divUp(maxBlocks, kMtRoundBlocks);
-      const uint64_t slots = 4ull * numComputeUnits();
-      uint32_t rounds = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(roundsPerElem, (uint64_t)roundsPerElem * grid.y / slots));
-      while (rounds > 1u && roundsPerElem % rounds != 0u) --rounds;  // equal slices
-      const uint32_t sliceBlocks = rounds * kMtRoundBlocks;
-      DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode_mt<P, 0>), dim3(divUp(maxBlocks, sliceBlocks), grid.y), dim3(kMtThreads),
-                  decMtLdsBytes(P, 0), stream, a, sliceBlocks);
+      auto launch = [&](auto geom, auto kernel, uint32_t wgPerCu) {
+        typedef decltype(geom) G;
+        const uint32_t roundsPerElem = divUp(maxBlocks, G::kRoundBlocks);
+        const uint64_t slots = (uint64_t)wgPerCu * numComputeUnits();
+        uint32_t rounds = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(roundsPerElem, (uint64_t)roundsPerElem * grid.y / slots));
+        while (rounds > 1u && roundsPerElem % rounds != 0u) --rounds;  // equal slices
+        const uint32_t sliceBlocks = rounds * G::kRoundBlocks;
+        DGPU_LAUNCH("k_ans_decode", stream, kernel, dim3(divUp(maxBlocks, sliceBlocks), grid.y), dim3(G::kThreads), G::ldsBytes(P), stream, a, sliceBlocks);
+      };
+      switch (decodeMtVariant()) {
+        case 2: launch(MtGeom<1, 2048, 8>(), (k_ans_decode_mt<P, 0, 1, 2048, 8>), 4); break;  // one chain, 2 KiB rings: k_ans_decode's geometry
+        case 3: launch(MtGeom<2, 2048, 4>(), (k_ans_decode_mt<P, 0, 2, 2048, 4>), 4); break;  // two chains, 2 KiB rings, 4 wavefronts
+        default: launch(MtGeom<2, 1024, 8>(), (k_ans_decode_mt<P, 0, 2, 1024, 8>), 4); break; // two chains, 1 KiB rings
+      }
     }
   } else {
     // DGPU_DEC_LDS_PAD (experiment knob): extra dynamic LDS per workgroup, i.e. fewer workgroups per CU -- the
