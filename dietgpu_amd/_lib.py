@@ -50,6 +50,8 @@ _SIGS = {
     "dgpu_debug_set_absent_workgroups": (None, [u32]),
     "dgpu_debug_set_param_cache": (None, [i32]),
     "dgpu_debug_set_fused": (None, [i32]),
+    "dgpu_has_fused": (i32, []),
+    "dgpu_release_graph_state": (i32, []),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)

@@ -14,11 +14,17 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "format.h"
 #include "kernels_decode.h"
+#ifndef DGPU_WITH_DEC_MT
+#define DGPU_WITH_DEC_MT 0
+#endif
+#if DGPU_WITH_DEC_MT
 #include "kernels_decode_mt.h"
+#endif
 #include "kernels_encode.h"
 #include "kernels_encode_fused.h"
 #include "kernels_pairs.h"
@@ -35,6 +41,7 @@ struct ChecksumMismatch {
   uint32_t expected, got;
 };
 thread_local std::vector<ChecksumMismatch> g_mismatches;
+thread_local const char* g_captureHint = nullptr;  // why a call cannot be captured into a HIP graph (set next to the error)
 
 int fail(int code, const std::string& msg) {
   g_lastError = msg;
@@ -143,6 +150,9 @@ struct StreamState {
   // encoder's 65536 ready flags (epoch-valued) and its ticket / exit counters (zero at rest)
   uint32_t* counters = nullptr;
   uint32_t fusedEpoch = 0;  // value the ready flags of the last fused call were raised to
+  // a call was CAPTURED into a HIP graph with pointers into this state (slab, counters): the graph replays without
+  // passing through the library, so the state is never trimmed or released implicitly (dgpu_release_graph_state)
+  bool graphPinned = false;
 
   void releaseDeviceMemory() {
     for (void* p : retired) (void)hipFree(p);
@@ -158,49 +168,48 @@ struct StreamState {
 class StreamRegistry {
  public:
   static constexpr size_t kMaxStreams = 32;
-  // Returns the state of (current device, stream), creating it if necessary.
-  StreamState* get(hipStream_t stream, hipError_t* err) {
-    std::lock_guard<std::mutex> g(mu_);
-    int dev = 0;
-    *err = hipGetDevice(&dev);
-    if (*err != hipSuccess) return nullptr;
-    auto key = std::make_pair(dev, stream);
-    auto it = states_.find(key);
-    if (it == states_.end()) {
-      if (states_.size() >= kMaxStreams) trimLocked();
-      StreamState* s = new StreamState();
-      s->device = dev;
-      s->stream = stream;
-      it = states_.emplace(key, s).first;
+  // Returns the state of (current device, stream) with its `busy` mutex HELD, creating the state if necessary.
+  // `busy` is taken (try_lock) while the registry mutex is held, so trimLocked() / release() -- which only drop
+  // states whose `busy` they can take -- can never delete a state between its lookup and its use.  A state that is
+  // busy (another host thread is enqueueing on the same stream) is waited for with the registry mutex released.
+  StreamState* acquire(hipStream_t stream, hipError_t* err) {
+    for (;;) {
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        int dev = 0;
+        *err = hipGetDevice(&dev);
+        if (*err != hipSuccess) return nullptr;
+        auto key = std::make_pair(dev, stream);
+        auto it = states_.find(key);
+        if (it == states_.end()) {
+          if (states_.size() >= kMaxStreams) trimLocked();
+          StreamState* s = new StreamState();
+          s->device = dev;
+          s->stream = stream;
+          it = states_.emplace(key, s).first;
+        }
+        if (it->second->busy.try_lock()) {
+          it->second->lastUse = ++clock_;
+          return it->second;
+        }
+      }
+      std::this_thread::yield();
     }
-    it->second->lastUse = ++clock_;
-    return it->second;
   }
   // Frees the device memory kept for `stream` on the current device (all streams
   // of all devices if `all`).  Synchronises first.  Returns the number of states released.
-  int release(hipStream_t stream, bool all) {
+  // States captured into a HIP graph (graphPinned) are only released when `includeGraphPinned`.
+  int release(hipStream_t stream, bool all, bool includeGraphPinned = false) {
     std::lock_guard<std::mutex> g(mu_);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
-    int n = 0;
-    for (auto it = states_.begin(); it != states_.end();) {
+    std::vector<std::map<std::pair<int, hipStream_t>, StreamState*>::iterator> victims;
+    for (auto it = states_.begin(); it != states_.end(); ++it) {
       StreamState* s = it->second;
       const bool match = all || (it->first.first == dev && it->first.second == stream);
-      if (match && s->busy.try_lock()) {
-        int prev = dev;
-        (void)hipSetDevice(s->device);
-        (void)hipDeviceSynchronize();
-        s->releaseDeviceMemory();
-        (void)hipSetDevice(prev);
-        s->busy.unlock();
-        delete s;
-        it = states_.erase(it);
-        ++n;
-      } else {
-        ++it;
-      }
+      if (match && (includeGraphPinned || !s->graphPinned) && s->busy.try_lock()) victims.push_back(it);
     }
-    return n;
+    return dropLocked(victims, dev);
   }
   size_t size() {
     std::lock_guard<std::mutex> g(mu_);
@@ -208,28 +217,49 @@ class StreamRegistry {
   }
 
  private:
-  // Drops the least recently used half of the idle states (device synchronise first:
-  // nothing enqueued earlier can still be using their memory afterwards).
-  void trimLocked() {
-    std::vector<std::pair<uint64_t, std::pair<int, hipStream_t>>> idle;
-    for (auto& kv : states_) idle.push_back({kv.second->lastUse, kv.first});
-    std::sort(idle.begin(), idle.end());
-    int cur = 0;
-    (void)hipGetDevice(&cur);
-    size_t dropped = 0;
-    for (auto& e : idle) {
-      if (dropped >= kMaxStreams / 2) break;
-      StreamState* s = states_[e.second];
-      if (!s->busy.try_lock()) continue;
-      (void)hipSetDevice(s->device);
-      (void)hipDeviceSynchronize();
-      s->releaseDeviceMemory();
+  typedef std::map<std::pair<int, hipStream_t>, StreamState*>::iterator Iter;
+  // `victims` hold their `busy`.  ONE device synchronise per device (nothing enqueued earlier can still be using
+  // the memory afterwards); a device that cannot be synchronised keeps its memory (leaked, never freed under work).
+  int dropLocked(const std::vector<Iter>& victims, int restoreDev) {
+    std::map<int, bool> synced;
+    for (Iter it : victims) {
+      const int d = it->second->device;
+      if (!synced.count(d)) synced[d] = hipSetDevice(d) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    }
+    int n = 0;
+    for (Iter it : victims) {
+      StreamState* s = it->second;
+      if (synced[s->device] && hipSetDevice(s->device) == hipSuccess) {
+        s->releaseDeviceMemory();
+      } else {
+        (void)hipGetLastError();
+        s->slab = nullptr;  // cannot prove idleness: leak rather than free under running kernels
+        s->counters = nullptr;
+        s->retired.clear();
+      }
       s->busy.unlock();
       delete s;
-      states_.erase(e.second);
-      ++dropped;
+      states_.erase(it);
+      ++n;
     }
-    (void)hipSetDevice(cur);
+    (void)hipSetDevice(restoreDev);
+    return n;
+  }
+  // Drops the least recently used half of the idle states that no HIP graph refers to.
+  void trimLocked() {
+    std::vector<std::pair<uint64_t, Iter>> idle;
+    for (auto it = states_.begin(); it != states_.end(); ++it) {
+      if (!it->second->graphPinned) idle.push_back({it->second->lastUse, it});
+    }
+    std::sort(idle.begin(), idle.end(), [](const std::pair<uint64_t, Iter>& a, const std::pair<uint64_t, Iter>& b) { return a.first < b.first; });
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    std::vector<Iter> victims;
+    for (auto& e : idle) {
+      if (victims.size() >= kMaxStreams / 2) break;
+      if (e.second->second->busy.try_lock()) victims.push_back(e.second);
+    }
+    dropLocked(victims, cur);
   }
   std::mutex mu_;
   uint64_t clock_ = 0;
@@ -253,19 +283,30 @@ class StreamLease {
   }
   StreamState* state(hipError_t* err) {
     if (!state_) {
-      StreamState* s = streamRegistry().get(stream_, err);
+      StreamState* s = streamRegistry().acquire(stream_, err);  // returns with `busy` held
       if (!s) return nullptr;
-      s->busy.lock();
       state_ = s;
+      if (capturing()) s->graphPinned = true;
     }
     *err = hipSuccess;
     return state_;
   }
   hipStream_t stream() const { return stream_; }
+  // Is the caller's stream being captured into a HIP graph?  Then nothing may synchronise or allocate, and every
+  // library-owned address the kernels receive must stay valid for the life of the graph.
+  bool capturing() {
+    if (capturing_ < 0) {
+      hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+      capturing_ = (hipStreamIsCapturing(stream_, &st) == hipSuccess && st == hipStreamCaptureStatusActive) ? 1 : 0;
+      if (capturing_ == 0) (void)hipGetLastError();
+    }
+    return capturing_ == 1;
+  }
 
  private:
   hipStream_t stream_;
   StreamState* state_ = nullptr;
+  int capturing_ = -1;
 };
 
 // Temp memory: bump allocation out of the caller's region; what does not fit
@@ -317,8 +358,9 @@ class TempArena {
     if (!overflowUsed_) {
       overflowUsed_ = true;
       // first overflow allocation of this call: slabs retired by EARLIER calls can go
-      // (their kernels precede everything this call enqueues on the stream)
-      if (!s->retired.empty()) {
+      // (their kernels precede everything this call enqueues on the stream) -- not while the stream is being
+      // captured: a synchronise would invalidate the capture, they wait for the next plain call
+      if (!s->retired.empty() && !lease_.capturing()) {
         *err = hipStreamSynchronize(lease_.stream());
         if (*err != hipSuccess) return nullptr;
         for (void* p : s->retired) (void)hipFree(p);
@@ -326,6 +368,13 @@ class TempArena {
       }
     }
     if (overflowHead_ + need > s->slabCap) {
+      if (lease_.capturing()) {
+        // growing the slab means hipMalloc in the middle of a stream capture
+        *err = hipErrorStreamCaptureUnsupported;
+        g_captureHint = "temp memory: the library-owned overflow slab would have to grow while the stream is being "
+                        "captured into a HIP graph; pass enough temp memory, or run the same call once before capturing";
+        return nullptr;
+      }
       const size_t cap = std::max<size_t>(std::max(2 * s->slabCap, need + (need >> 2)), (size_t)8 << 20);
       void* p = nullptr;
       *err = hipMalloc(&p, cap);
@@ -356,7 +405,7 @@ class TempArena {
   do {                                                                       \
     hipError_t e_ = hipSuccess;                                              \
     var = (arena).alloc<T>((count), &e_);                                    \
-    if (!var) return fail(DGPU_ERR_HIP, std::string("temp alloc: ") + hipGetErrorString(e_)); \
+    if (!var) return fail(DGPU_ERR_HIP, std::string("temp alloc: ") + (e_ == hipErrorStreamCaptureUnsupported && g_captureHint ? g_captureHint : hipGetErrorString(e_))); \
   } while (0)
 
 // ---------------------------------------------------------------------------
@@ -395,10 +444,14 @@ class ParamCache {
     std::vector<hipStream_t> hitStreams;  // every stream that hit this entry since its upload
     bool syncAllBeforeReuse = false;      // completion could not be tracked: device synchronise before reuse
     bool everUsed = false;
+    bool graphPinned = false;             // a HIP graph holds entry->dev: never evicted (dgpu_release_graph_state)
   };
 
   // Returns a pinned entry holding `block`; *miss tells the caller to record `released`.
-  hipError_t acquire(const uint8_t* block, size_t bytes, hipStream_t stream, Entry** out, bool* miss) {
+  // `capturing`: the stream is being captured into a HIP graph.  The graph will replay with entry->dev baked into
+  // its kernel arguments without ever passing through acquire() again, so the entry is pinned for good; and nothing
+  // here may synchronise, allocate or blit then, so only a block that is already resident (a hit) can be captured.
+  hipError_t acquire(const uint8_t* block, size_t bytes, hipStream_t stream, Entry** out, bool* miss, bool capturing = false) {
     const uint64_t h = hashBlock(block, bytes);
     std::lock_guard<std::mutex> g(mu_);
     int dev = 0;
@@ -415,6 +468,10 @@ class ParamCache {
         }
         en->lastUse = clock_;
         en->pins++;
+        if (capturing && !en->graphPinned) {
+          en->graphPinned = true;
+          en->pins++;  // never released: the entry stays where it is for the life of the graph
+        }
         if (std::find(en->hitStreams.begin(), en->hitStreams.end(), stream) == en->hitStreams.end()) {
           en->hitStreams.push_back(stream);
         }
@@ -422,6 +479,11 @@ class ParamCache {
         *miss = false;
         return hipSuccess;
       }
+    }
+    if (capturing) {
+      g_captureHint = "the call's pointer / size arrays are not resident on the device yet and cannot be uploaded while the "
+                      "stream is being captured into a HIP graph: run the same call once before capturing";
+      return hipErrorStreamCaptureUnsupported;
     }
     // miss: least recently used unpinned entry, or a new one while the cache is small
     Entry* victim = nullptr;
@@ -491,6 +553,22 @@ class ParamCache {
     *out = victim;
     *miss = true;
     return hipSuccess;
+  }
+
+  // Makes the blocks HIP graphs were captured with evictable again (the caller has destroyed those graphs).
+  int releaseGraphPins() {
+    std::lock_guard<std::mutex> g(mu_);
+    int n = 0;
+    for (auto& kv : perDevice_) {
+      for (Entry* en : kv.second) {
+        if (en->graphPinned) {
+          en->graphPinned = false;
+          en->pins--;
+          ++n;
+        }
+      }
+    }
+    return n;
   }
 
   void release(Entry* en, bool miss, hipStream_t stream) {
@@ -648,6 +726,15 @@ void batchShape(const HostParams& hp, uint32_t* uniformSize, bool* aligned16) {
   *aligned16 = al;
 }
 
+bool streamIsCapturing(hipStream_t stream) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &st) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return st == hipStreamCaptureStatusActive;
+}
+
 int uploadParams(
     ParamLease& lease, hipStream_t stream, const HostParams& hp,
     const uint64_t** inPtrs_dev, const uint64_t** outPtrs_dev, const uint32_t** sizes_dev,
@@ -664,7 +751,12 @@ int uploadParams(
   if (nIb) memcpy(h + (nIn + nOut) * 8 + alignUp(nSz * 4, 8), hp.inBytes.data(), nIb * 4);
   ParamCache::Entry* entry = nullptr;
   bool miss = false;
-  DGPU_HIP(paramCache().acquire(h, bytes, stream, &entry, &miss));
+  {
+    const bool capturing = streamIsCapturing(stream);
+    const hipError_t ae = paramCache().acquire(h, bytes, stream, &entry, &miss, capturing);
+    if (ae == hipErrorStreamCaptureUnsupported && capturing && g_captureHint) return fail(DGPU_ERR_HIP, std::string("HIP graph capture: ") + g_captureHint);
+    DGPU_HIP(ae);
+  }
   lease.bind(entry, miss, stream);
   uint8_t* dev = (uint8_t*)entry->dev;
   *inPtrs_dev = nIn ? (const uint64_t*)dev : nullptr;
@@ -863,6 +955,10 @@ int arrivalCounters(StreamLease& lease, uint32_t** out, uint32_t** acc) {
   StreamState* s = lease.state(&e);
   if (!s) return fail(DGPU_ERR_HIP, std::string("stream state: ") + hipGetErrorString(e));
   if (!s->counters) {
+    if (lease.capturing()) {
+      return fail(DGPU_ERR_HIP, "HIP graph capture: the stream's hand-off counters do not exist yet and cannot be allocated while "
+                                "the stream is being captured: run the same call once before capturing");
+    }
     uint32_t* p = nullptr;
     const size_t words = kCounterWordsArrive + kCounterWordsAcc + kCounterWordsReady + kCounterWordsTickets;
     DGPU_HIP(hipMalloc((void**)&p, words * sizeof(uint32_t)));
@@ -882,8 +978,15 @@ int arrivalCounters(StreamLease& lease, uint32_t** out, uint32_t** acc) {
 
 // ---------------------------------------------------------------------------
 // Fused histogram + encode (kernels_encode_fused.h): taken for uniform batches.
+// The kernel is only compiled into builds made with -DDGPU_WITH_FUSED=1 (tools/build_variant.py fused
+// -DDGPU_WITH_FUSED=1): it is parity-green and halves the HBM reads of the encode call, but measured slower than the
+// two-kernel path on every workload, so the default library does not carry it.
+#ifndef DGPU_WITH_FUSED
+#define DGPU_WITH_FUSED 0
+#endif
 std::atomic<int> g_fusedMode{-1};  // -1: environment DGPU_FUSED (default off), 0 / 1: forced (dgpu_debug_set_fused)
 bool fusedEnabled() {
+  if (!DGPU_WITH_FUSED) return false;
   const int m = g_fusedMode.load();
   if (m >= 0) return m != 0;
   static const bool env = [] {
@@ -893,6 +996,7 @@ bool fusedEnabled() {
   return env;
 }
 
+#if DGPU_WITH_FUSED
 template <int P, uint32_t FT>
 uint32_t fusedGridPF(uint32_t tickets) {
   static const uint32_t perCu = [] {
@@ -914,6 +1018,7 @@ int launchFusedPF(const FusedArgs& a, uint32_t grid, hipStream_t stream) {
   return DGPU_OK;
 }
 
+#endif
 // Is the batch one the fused kernel takes?  (uniformSize: every element has that many symbols, 0 = ragged)
 bool fusedEligible(uint32_t B, uint32_t uniformSize, bool inputsAligned16, const uint32_t* hist_dev) {
   if (!fusedEnabled() || hist_dev || !inputsAligned16 || B == 0 || B > kCounterWordsReady) return false;
@@ -922,6 +1027,7 @@ bool fusedEligible(uint32_t B, uint32_t uniformSize, bool inputsAligned16, const
   return uniformSize / kTileSymbols <= kFusedMaxTiles;
 }
 
+#if DGPU_WITH_FUSED
 int encodeFused(
     TempArena& arena, StreamLease& lease, hipStream_t stream, int P, bool useChecksum, uint32_t B,
     const BatchView& in, const BatchView& archives, uint32_t floatType, uint32_t size,
@@ -997,6 +1103,8 @@ int encodeFused(
   return rc;
 }
 
+#endif
+
 // Shared tail of every encode entry point: [checksum] -> histogram (+ fused
 // normalisation) -> encode.  `in` holds raw bytes (floatType == 0: the ANS
 // archive is the whole output) or float words (floatType != 0: the encoder
@@ -1024,10 +1132,13 @@ int encodeCommon(
     DGPU_HIP(hipGetLastError());
   }
 
-  if (fusedEligible(B, uniformSize, inputsAligned16, hist_dev)) {
+#if DGPU_WITH_FUSED
+  // (not under stream capture: the epoch the ready flags are compared with would be baked into the graph)
+  if (fusedEligible(B, uniformSize, inputsAligned16, hist_dev) && !lease.capturing()) {
     return encodeFused(arena, lease, stream, P, useChecksum, B, in, archives, floatType, uniformSize, checksumTemp,
                        outSize_dev);
   }
+#endif
 
   DGPU_ALLOC(table, uint4, arena, (size_t)B * kNumSymbols);
   DGPU_ALLOC(tileDesc, uint64_t, arena, (size_t)B * std::max(maxTiles, 1u));
@@ -1209,13 +1320,16 @@ int floatCompressImpl(
   return rc;
 }
 
-// DGPU_DEC_MT: which decoder raw-byte elements of more than 8 blocks get (kernels_decode_mt.h): 0 = k_ans_decode's
-// 16-block tiles, 1 = two chains per wavefront on 1 KiB rings, 2 = one chain on 2 KiB rings, 3 = two chains on 2 KiB
-// rings with 4-wavefront workgroups; environment DGPU_DEC_MT overrides (A/B runs)
+// k_ans_decode_mt (kernels_decode_mt.h: several blocks per wavefront, scalar ring maintenance, element slices per
+// workgroup) is only compiled into builds made with -DDGPU_WITH_DEC_MT=1: byte-exact, but SLOWER than k_ans_decode on
+// every geometry tried ("Config 2").  There DGPU_DEC_MT selects the decoder raw-byte elements
+// of more than 8 blocks get: 0 = k_ans_decode's 16-block tiles, 1 = two chains per wavefront on 1 KiB rings, 2 = one
+// chain on 2 KiB rings, 3 = two chains on 2 KiB rings with 4-wavefront workgroups.
 #ifndef DGPU_DEC_MT
 #define DGPU_DEC_MT 1
 #endif
 int decodeMtVariant() {
+  if (!DGPU_WITH_DEC_MT) return 0;
   static const int v = [] {
     const char* e = getenv("DGPU_DEC_MT");
     return e ? atoi(e) : (int)DGPU_DEC_MT;
@@ -1238,7 +1352,8 @@ int launchDecodePF(const DecodeArgs& a, uint32_t tileBlocks, dim3 grid, hipStrea
   } else if (tileBlocks == kDecBlocksPerSmallTile) {
     DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode<P, FT, kDecBlocksPerSmallTile>), grid, dim3(kDecBlocksPerSmallTile * 32u),
                 decLdsBytes(P, FT, kDecBlocksPerSmallTile), stream, a);
-  } else if (FT == 0 && decodeMtVariant() != 0) {
+#if DGPU_WITH_DEC_MT
+  } else if (tileBlocks == kDecBlocksPerTile && FT == 0 && decodeMtVariant() != 0) {
     // raw bytes, elements of more than 8 blocks: several blocks per wavefront / scalar ring maintenance
     // (kernels_decode_mt.h).  A workgroup takes a slice of an element: as many rounds as leaves every CU its
     // share of workgroups.
@@ -1259,6 +1374,7 @@ int launchDecodePF(const DecodeArgs& a, uint32_t tileBlocks, dim3 grid, hipStrea
         default: launch(MtGeom<2, 1024, 8>(), (k_ans_decode_mt<P, 0, 2, 1024, 8>), 4); break; // two chains, 1 KiB rings
       }
     }
+#endif
   } else {
     // DGPU_DEC_LDS_PAD (experiment knob): extra dynamic LDS per workgroup, i.e. fewer workgroups per CU -- the
     // occupancy scaling of the 16-block decoder (tools/occupancy_scaling.sh)
@@ -1452,6 +1568,11 @@ extern "C" {
 void dgpu_debug_set_absent_workgroups(uint32_t modulo) { g_absentModulo.store(modulo); }
 void dgpu_debug_set_param_cache(int on) { g_paramCacheEnabled.store(on != 0); }
 void dgpu_debug_set_fused(int mode) { g_fusedMode.store(mode < 0 ? -1 : (mode != 0)); }
+int dgpu_has_fused(void) { return DGPU_WITH_FUSED; }
+int dgpu_release_graph_state(void) {
+  const int n = paramCache().releaseGraphPins();
+  return n + streamRegistry().release(nullptr, true, true);
+}
 
 int dgpu_release_stream_state(void* stream) { return streamRegistry().release((hipStream_t)stream, false); }
 int dgpu_release_all_stream_state(void) { return streamRegistry().release(nullptr, true); }

@@ -294,13 +294,24 @@ void dgpu_debug_set_absent_workgroups(uint32_t modulo);
  * steady-state one. */
 void dgpu_debug_set_param_cache(int on);
 
-/* Measurement / test hook: uniform batches (every element the same whole number of 32 Ki-symbol
- * tiles, <= 32 of them, 16-byte aligned inputs, no caller histogram) are encoded by ONE kernel that
- * reads the input once (histogram + normalisation + encode fused).
- * 0 forces the two-kernel path (histogram kernel, then encode kernel), 1 forces the fused one where
- * eligible, -1 restores the default (environment DGPU_FUSED, on unless "0").  Archives are
- * byte-identical either way. */
+/* Test hook of the single-read encoder (k_ans_encode_fused), which only builds made with
+ * -DDGPU_WITH_FUSED=1 contain (dgpu_has_fused() == 1; the default library does not: the kernel measured slower
+ * than the two-kernel path).  There, uniform batches (every element the same whole number of 32 Ki-symbol tiles,
+ * <= 32 of them, 16-byte aligned inputs, no caller histogram) can be encoded by ONE kernel that reads the input
+ * once.  0 forces the two-kernel path, 1 the fused one where eligible, -1 restores the default (off unless the
+ * environment has DGPU_FUSED=1).  Archives are byte-identical either way.  A no-op without the kernel. */
 void dgpu_debug_set_fused(int mode);
+int dgpu_has_fused(void);
+
+/* HIP graphs.  A call made while its stream is being captured (hipStreamBeginCapture) bakes library-owned device
+ * addresses into the graph: the resident copy of its pointer / size arrays and the stream's hand-off counters and
+ * overflow slab.  The library pins them -- they are neither evicted nor trimmed nor released by
+ * dgpu_release_stream_state / dgpu_release_all_stream_state -- until the caller, having destroyed every such graph,
+ * calls dgpu_release_graph_state() (returns the number of objects unpinned / released; synchronises the devices).
+ * Nothing can be uploaded or allocated under capture: a call whose arrays are not resident yet, or whose temp
+ * memory overflows into a slab that would have to grow, fails with DGPU_ERR_HIP and a message that says so; running
+ * the same call once before capturing makes everything resident. */
+int dgpu_release_graph_state(void);
 
 #ifdef __cplusplus
 }

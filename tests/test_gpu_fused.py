@@ -16,7 +16,11 @@ TILE = 8 * 4096
 
 @pytest.fixture(autouse=True)
 def fused_on(dg):
-    # the fused kernel is opt-in (DGPU_FUSED=1 / dgpu_debug_set_fused(1)): these tests force it
+    # the kernel is only in builds made with -DDGPU_WITH_FUSED=1 (python tools/build_variant.py fused
+    # -DDGPU_WITH_FUSED=1; run with DGPU_LIB=dietgpu_amd/lib/v_fused.so): the default library does not carry it
+    if not dg.lib().dgpu_has_fused():
+        pytest.skip("this build has no k_ans_encode_fused (DGPU_WITH_FUSED=0, the default)")
+    # ... and there it is opt-in (DGPU_FUSED=1 / dgpu_debug_set_fused(1)): these tests force it
     dg.lib().dgpu_debug_set_fused(1)
     yield
     dg.lib().dgpu_debug_set_fused(-1)

@@ -69,3 +69,71 @@ def test_encode_decode_captured_in_a_hip_graph(as_float):
         for i in range(B):
             k = int(sizes[i])
             assert torch.equal(ref_comp[i, :k], comp[i, :k])
+
+
+def test_graph_survives_parameter_cache_churn_and_reports_unwarmed_capture():
+    """a captured call bakes the device copy of its pointer / size arrays (and the stream's counters)
+    into the graph; a replay never passes through the library, so nothing refreshes the cache entry.  The entry is
+    pinned at capture time: 40 other distinct pointer-list calls (the cache holds 16 blocks) must not evict it.
+    And a call whose arrays are NOT resident cannot be captured: it fails with a message that says so."""
+    import dietgpu_amd
+    from dietgpu_amd import ops
+
+    L = dietgpu_amd.lib()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    g0 = torch.Generator(device="cpu").manual_seed(11)
+    B, n = 6, 40_000
+    # ragged sizes + a shuffled order: a genuine pointer list (no arithmetic progression), so the call needs its
+    # parameter block on the device
+    xs = [torch.randn(n + 24 * ((i * 5) % B), generator=g0).to(torch.bfloat16).to(dev) for i in range(B)]
+    rows, cols = ops.max_float_compressed_output_size(xs)
+    comp = torch.empty((rows, cols), dtype=torch.uint8, device=dev)
+    sizes = torch.zeros((rows,), dtype=torch.int32, device=dev)
+    outs = [torch.empty_like(x) for x in xs]
+    status = torch.zeros((B,), dtype=torch.uint8, device=dev)
+    temp = torch.empty((128 << 20,), dtype=torch.uint8, device=dev)
+    order = [3, 0, 5, 1, 4, 2]
+
+    def roundtrip():
+        ops.compress_data(True, [xs[i] for i in order], False, temp, comp, sizes)
+        ops.decompress_data(True, [comp[k] for k in range(B)], [outs[i] for i in order], False, temp, status, None)
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    # (1) capture WITHOUT warm-up: refused with a clear message, the capture is abandoned cleanly
+    torch.cuda.synchronize()
+    graph0 = torch.cuda.CUDAGraph()
+    failed = None
+    try:
+        with torch.cuda.graph(graph0, stream=s):
+            roundtrip()
+    except Exception as e:  # the library's error surfaces through ops.check()
+        failed = str(e)
+    assert failed is not None and "before capturing" in failed, failed
+    torch.cuda.synchronize()
+    # (2) warm up, capture, churn the cache, replay
+    with torch.cuda.stream(s):
+        roundtrip()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        roundtrip()
+    torch.cuda.synchronize()
+    for k in range(40):
+        ys = [torch.randn(3000 + 16 * ((k + 7 * j) % 9), generator=g0).to(torch.bfloat16).to(dev) for j in range(3)]
+        c2, s2, _ = ops.compress_data(True, [ys[2], ys[0], ys[1]], False, temp)
+    torch.cuda.synchronize()
+    for x in xs:
+        x.copy_(torch.randn(x.numel(), generator=g0).to(torch.bfloat16))
+    for o in outs:
+        o.zero_()
+    status.zero_()
+    torch.cuda.synchronize()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert bool(status.all())
+    for x, o in zip(xs, outs):
+        assert torch.equal(x.view(torch.int16), o.view(torch.int16))
+    del graph
+    assert L.dgpu_release_graph_state() >= 1  # the pinned block(s) become evictable again
