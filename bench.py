@@ -200,16 +200,48 @@ def baseline_metric():
         return None
 
 
+def kernel_source_hash():
+    """sha256 over the sources the library is built from (dietgpu_amd/csrc/*, include/dietgpu_amd.h), the stamp
+    tools/make_traffic_json.py puts into profiles/*_hbm_traffic.json: ties the PMC passes to the build that ran
+    (the GPU box has no .git, so this is a content hash, not a commit id)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "dietgpu_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".h", ".hip", ".cpp")))
+    files.append(os.path.join(ROOT, "include", "dietgpu_amd.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+TRAFFIC_FILES = ("r03_hbm_traffic.json", "r02_hbm_traffic.json")
+
+
 def measured_traffic(workload, kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (cannot be collected inside this
-    process: rocprofv3 wraps the command).  None when no pass exists for this workload."""
-    path = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
-    try:
-        with open(path) as f:
-            rec = json.load(f)["workloads"][workload][kernel]
-        return rec.get("hbm_bytes_per_launch")
-    except (OSError, KeyError, ValueError):
-        return None
+    """HBM bytes per launch of `kernel` from the committed PMC passes (cannot be collected inside this process:
+    rocprofv3 wraps the command) -- ONLY when those passes were taken on the sources this build was made from
+    (`kernel_source_hash` stamped into the file by tools/make_traffic_json.py).  Returns (bytes or None, note)."""
+    want = kernel_source_hash()
+    seen = []
+    for name in TRAFFIC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            with open(path) as f:
+                doc = json.load(f)
+        except (OSError, ValueError):
+            continue
+        stamp = doc.get("kernel_source_hash")
+        seen.append(f"{name}: {stamp}")
+        if stamp != want:
+            continue
+        try:
+            return doc["workloads"][workload][kernel].get("hbm_bytes_per_launch"), f"profiles/{name} (kernel_source_hash {stamp} = this build)"
+        except KeyError:
+            continue
+    return None, f"no PMC pass for this build (kernel_source_hash {want}; on file: {', '.join(seen) or 'none'})"
 
 
 def cpu_baseline(kind, prob_bits, budget_s=12.0):
@@ -343,6 +375,80 @@ def run_collective(args, data, ft, desc, world, rank, device, D):
     dist.destroy_process_group()
 
 
+# A100 figures read off the reference's README plots (batch of one tensor, +-5 GB/s)
+A100_README = {
+    "bfloat16": {"compress": {1: 20, 16: 180, 128: 302, 1024: 345}, "decompress": {1: 23, 16: 257, 128: 488, 1024: 607}},
+    "float16": {"compress": {1: 20, 16: 148, 128: 261, 1024: 305}, "decompress": {1: 20, 16: 221, 128: 384, 1024: 489}},
+}
+
+
+def run_reference_protocol(args, device):
+    """The reference's own benchmark (dietgpu/benchmark.py:35-86,156-175; README.md:94 plots): ONE tensor of
+    1 M / 16 M / 128 M / 1024 M floats ~ N(0,1), bf16 and fp16, through torch.ops.dietgpu.compress_data /
+    decompress_data with a 384 MiB temp_mem, first run discarded, mean of `runs`, compress and decompress timed
+    separately with events around the op, every run validated bit for bit.  GB/s = uncompressed bytes / time."""
+    import dietgpu_amd
+
+    ops = dietgpu_amd.load_torch_ops()
+    temp = torch.empty([384 * 1024 * 1024], dtype=torch.uint8, device=device)
+    rows_out = []
+    sizes_m = [int(x) for x in args.ref_sizes.split(",")]
+    runs = 3
+    for dt, name in ((torch.bfloat16, "bfloat16"), (torch.float16, "float16")):
+        for m in sizes_m:
+            n = m * 1024 * 1024
+            g = torch.Generator(device=device).manual_seed(1234 + m)
+            # (torch.normal in 64 M-element pieces: a 1024 M-element fp32 intermediate would be 4 GiB more)
+            t = torch.empty([n], dtype=dt, device=device)
+            piece = 64 * 1024 * 1024
+            for lo in range(0, n, piece):
+                hi = min(n, lo + piece)
+                t[lo:hi] = torch.randn([hi - lo], generator=g, device=device, dtype=torch.float32).to(dt)
+            ts = [t]
+            r, c = ops.max_float_compressed_output_size(ts)
+            comp = torch.empty([r, c], dtype=torch.uint8, device=device)
+            sizes = torch.zeros([1], dtype=torch.int32, device=device)
+            out = torch.empty_like(t)
+            status = torch.empty([1], dtype=torch.uint8, device=device)
+            osz = torch.empty([1], dtype=torch.int32, device=device)
+            ct = dct = 0.0
+            for i in range(1 + runs):
+                s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s0.record()
+                comp, sizes, _ = ops.compress_data(True, ts, False, temp, comp, sizes)
+                e0.record()
+                torch.cuda.synchronize()
+                if i > 0:
+                    ct += s0.elapsed_time(e0)
+                comp_ts = [*comp]
+                s1, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s1.record()
+                ops.decompress_data(True, comp_ts, [out], False, temp, status, osz)
+                e1.record()
+                torch.cuda.synchronize()
+                if i > 0:
+                    dct += s1.elapsed_time(e1)
+                assert bool(status.all().item()) and int(osz[0].item()) == n
+                assert torch.equal(t.view(torch.int16), out.view(torch.int16)), "round trip is not bit-exact"
+            ct, dct = ct / runs, dct / runs
+            nbytes = n * 2
+            row = {"dtype": name, "mega_floats": m, "compress_ms": round(ct, 4), "compress_GBps": round(nbytes / ct / 1e6, 1),
+                   "decompress_ms": round(dct, 4), "decompress_GBps": round(nbytes / dct / 1e6, 1),
+                   "ratio": round(int(sizes[0].item()) / nbytes, 4),
+                   "a100_readme_compress_GBps": A100_README[name]["compress"].get(m),
+                   "a100_readme_decompress_GBps": A100_README[name]["decompress"].get(m)}
+            rows_out.append(row)
+            del t, comp, out, comp_ts, ts
+            torch.cuda.empty_cache()
+    print(json.dumps({
+        "metric": "reference_protocol_float_codec_GBps",
+        "protocol": "dietgpu/benchmark.py:35-86,156-175: batch of ONE tensor ~ N(0,1), torch.ops.dietgpu.compress_data / "
+                    "decompress_data with a 384 MiB temp_mem, first run discarded, mean of 3, events around each op, "
+                    "GB/s = uncompressed bytes / time, every run validated bit for bit",
+        "hardware": "1 x MI355X (A100 columns: read off the reference's README plots, BASELINE.md section 1)",
+        "rows": rows_out, "round_trip_bit_exact": True}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -361,6 +467,15 @@ def main():
                     help="instead of the codec step: plain vs compressed all-gather of every rank's shard "
                          "(dietgpu_amd.distributed.CompressedAllGatherPlan), effective GB/s per rank")
     ap.add_argument("--chunks", type=int, default=4, help="--collective: pipeline chunks per shard")
+    ap.add_argument("--rotate", type=int, default=4,
+                    help="distinct {input, archive, output} buffer sets of the rotating-buffer figure "
+                         "(ms_per_step_rotating); 1 = skip it")
+    ap.add_argument("--reference-protocol", action="store_true",
+                    help="instead of the batched step: the reference's own benchmark protocol (benchmark.py:35-86, "
+                         "156-175) -- batch of ONE tensor, 1 M / 16 M / 128 M / 1024 M floats, bf16 and fp16, through "
+                         "torch.ops.dietgpu.compress_data / decompress_data with temp_mem, compress and decompress "
+                         "GB/s separately; one JSON line with the table")
+    ap.add_argument("--ref-sizes", default="1,16,128,1024", help="--reference-protocol: tensor sizes in Mi floats")
     ap.add_argument("--timeline", action="store_true",
                     help="only the timed steps (no per-phase timing / kernel profile): for rocprofv3 timelines")
     args = ap.parse_args()
@@ -409,6 +524,10 @@ def main():
 
         D.init(backend=args.dist_backend, device=device)  # "nccl" is RCCL on ROCm
 
+    if args.reference_protocol:
+        if distributed:
+            sys.exit("bench.py --reference-protocol: single GPU only (the reference's benchmark is)")
+        return run_reference_protocol(args, device)
     data, ft, _, prob_bits, desc = make_workload(args.workload, args.batch, 1234 + rank, device, args.elems)
     if args.prob_bits:
         prob_bits = args.prob_bits
@@ -426,6 +545,16 @@ def main():
     for _ in range(args.warmup):
         codec.step()
     codec.verify()
+    # The driver's literal protocol first: W warm-up steps (just done), then K timed steps -- before the pre-roll below
+    # has settled the clocks.  Reported as `ms_per_step_no_preroll`.
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        codec.step()
+    fence()
+    elapsed_no_preroll = time.perf_counter() - t0
+    if distributed:
+        elapsed_no_preroll = D.max_over_ranks(elapsed_no_preroll, device)
     # Pre-roll: the GPU's clocks take tens of milliseconds of load to settle (the same build
     # measures 263 us per step over 20 steps after 3 warm-up steps, 223 us in steady state).  Whatever W and K
     # are, the timed region starts after at least ~0.1 s of the same work; the K timed steps are untouched.
@@ -487,6 +616,42 @@ def main():
             print(json.dumps({"ms_per_step": round(elapsed / args.steps * 1e3, 4)}))
         return
 
+    # ROTATING buffers: every step above re-codes the same 256 MiB, and the archive it writes (~180 MB) is smaller
+    # than the 256 MiB memory-side cache, so the decoder may find it there.  Here R distinct {input, archive,
+    # output} sets (different data) are coded round robin -- with the default shape each set touches ~0.7 GB and
+    # four of them 2.8 GB -- so neither an input nor an archive can still be cached when its turn comes again.
+    elapsed_rot, rot_sets, rot_bytes = None, 0, 0
+    if args.rotate > 1:
+        free_b = torch.cuda.mem_get_info(device)[0]
+        per_set = codec.in_bytes * 2 + codec.comp.numel()
+        rot_sets = int(max(1, min(args.rotate, (free_b - (2 << 30)) // max(per_set, 1) + 1)))
+        sets = [codec]
+        for r in range(1, rot_sets):
+            d2, _, _, _, _ = make_workload(args.workload, args.batch, 1234 + rank + 1000 * r, device, args.elems)
+            c2 = Codec(dg, d2, ft, prob_bits)
+            c2.temp = codec.temp  # one temp region: the calls are ordered on one stream
+            sets.append(c2)
+        for c2 in sets:
+            c2.step()
+        for c2 in sets[1:]:
+            c2.verify()
+        rot_bytes = sum(int(c2.sizes.to(torch.int64).sum().item()) + 2 * c2.in_bytes for c2 in sets)
+        for i in range(args.warmup):
+            sets[i % rot_sets].step()
+        fence()
+        t = time.perf_counter()
+        for i in range(args.steps):
+            sets[i % rot_sets].step()
+        fence()
+        elapsed_rot = time.perf_counter() - t
+        if distributed:
+            elapsed_rot = D.max_over_ranks(elapsed_rot, device)
+        for c2 in sets[1:]:
+            c2.verify()
+        del sets
+        for _ in range(args.warmup):
+            codec.step()
+
     enc_ms = timed(codec.encode, args.steps)
     dec_ms = timed(codec.decode, args.steps)
 
@@ -520,13 +685,15 @@ def main():
             roofline = {
                 "bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBPS, 4),
-                # the PMC passes were taken on the default shape only
-                "traffic": measured_traffic(args.workload, dom) if (args.batch == 256 and args.elems == 512 * 1024) else None,
                 "avg_us": kernels[dom]["avg_us"],
                 "algorithmic_bytes": algorithmic_bytes(dom, codec, comp_total),
-                "traffic_source": "profiles/r02_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                  "(tools/gpu_pmc.sh), (2*FETCH_SIZE + WRITE_SIZE) KiB per launch",
             }
+            # the PMC passes are taken on the default shape only, and count only for the build they were taken on
+            traffic, note = (measured_traffic(args.workload, dom) if (args.batch == 256 and args.elems == 512 * 1024)
+                             else (None, "PMC passes exist for the default shape only"))
+            roofline["traffic"] = traffic
+            roofline["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_pmc.sh), "
+                                          "(2*FETCH_SIZE + WRITE_SIZE) KiB per launch; " + note)
         # whole-step figure: algorithmic bytes of encode + decode over the step time
         E = codec.B * codec.elems
         if ft:
@@ -547,6 +714,15 @@ def main():
             "warmup": args.warmup,
             "preroll_steps": preroll,
             "ms_per_step": round(ms_per_step, 4),
+            # the same K steps timed straight after the W warm-up steps, BEFORE the pre-roll (the literal protocol)
+            "ms_per_step_no_preroll": round(elapsed_no_preroll / args.steps * 1e3, 4),
+            # K steps over `rotating_sets` distinct {input, archive, output} sets (nothing can stay in the
+            # 256 MiB memory-side cache between two uses); null when --rotate 1
+            "ms_per_step_rotating": round(elapsed_rot / args.steps * 1e3, 4) if elapsed_rot else None,
+            "rotating_sets": rot_sets,
+            "rotating_footprint_bytes": rot_bytes,
+            "step_frac_of_hbm_peak_rotating": (round(step_alg / (elapsed_rot / args.steps) / 1e9 / HBM_PEAK_GBPS, 4)
+                                               if elapsed_rot else None),
             "ms_per_step_pointer_list": round(elapsed_ptrlist / args.steps * 1e3, 4),
             "ms_per_step_param_upload_every_call": round(elapsed_uncached / args.steps * 1e3, 4),
             "higher_is_better": True,

@@ -37,6 +37,8 @@ _SIGS = {
     "dgpu_ans_decode_batch_split_size_bounded": (i32, [vp, sz, vp, i32, i32, u32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dgpu_float_decompress_bounded": (i32, [vp, sz, vp, u32, i32, i32, u32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dgpu_float_decompress_split_size_bounded": (i32, [vp, sz, vp, u32, i32, i32, u32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dgpu_float_compress_stride_capped": (i32, [vp, sz, vp, u32, i32, i32, u32, vp, u32, u32, vp, u32, u32, vp, vp]),
+    "dgpu_float_decompress_stride_bounded": (i32, [vp, sz, vp, u32, i32, i32, u32, vp, u32, u32, vp, u32, u32, vp, vp, vp, vp]),
     "dgpu_float_get_compressed_info": (i32, [vp, sz, vp, u32, vp, vp, vp, vp]),
     "dgpu_float_get_compressed_info_device": (i32, [vp, u32, vp, vp, vp, vp]),
     "dgpu_ans_histogram_batch_stride": (i32, [u32, vp, u32, u32, vp, vp]),

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <climits>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -688,14 +689,19 @@ uint32_t gridX(uint32_t maxBytes, uint32_t bytesPerBlock, uint32_t cap) {
 bool validProbBits(int p) { return p == 9 || p == 10 || p == 11; }
 bool validFloatType(uint32_t ft) { return ft == kFloat16 || ft == kBFloat16 || ft == kFloat32; }
 
+// getMaxCompressedSize, GpuANSEncode.cu:13-25 (block SIZE passed as block COUNT [sic]).  Upstream CHECKs the result
+// against INT32_MAX (GpuANSEncode.cu:22: inputs beyond 419 321 blocks = 1 717 538 816 bytes abort); here such a size
+// yields 0 and the encode entry points reject it.
+constexpr uint32_t kMaxEncodableBytes = 419321u * kBlockSize;
 uint32_t maxCompressedSizeHost(uint32_t bytes) {
-  // getMaxCompressedSize, GpuANSEncode.cu:13-25 (block SIZE passed as block COUNT [sic])
   uint32_t blocks = divUp(bytes, kBlockSize);
   size_t raw = ansOverhead(kBlockSize);
   raw += (size_t)roundUp(kBlockSize + kBlockSize / 4, 16) * blocks;
   raw = alignUp(raw, 16);
+  if (raw > (size_t)INT32_MAX) return 0u;
   return (uint32_t)raw;
 }
+bool encodableSize(uint32_t symbols) { return symbols <= kMaxEncodableBytes; }
 
 // Device batch description assembled by each entry point.
 struct DeviceBatch {
@@ -1116,7 +1122,8 @@ int encodeCommon(
     TempArena& arena, StreamLease& lease, hipStream_t stream, int P, bool useChecksum, uint32_t B,
     const BatchView& in, const BatchView& archives, uint32_t floatType, uint32_t maxSize,
     uint32_t uniformSize /* != 0: every element has this many symbols */, bool inputsAligned16,
-    const uint32_t* hist_dev /*may be null*/, uint32_t* outSize_dev) {
+    const uint32_t* hist_dev /*may be null*/, uint32_t* outSize_dev,
+    uint32_t outCapacity = 0xffffffffu /* bytes at every archive pointer; block data beyond it is dropped */) {
   const uint32_t wordBytes = floatType ? floatWordBytes(floatType) : 1u;
   const uint32_t maxTiles = tilesFor(maxSize);
 
@@ -1134,7 +1141,7 @@ int encodeCommon(
 
 #if DGPU_WITH_FUSED
   // (not under stream capture: the epoch the ready flags are compared with would be baked into the graph)
-  if (fusedEligible(B, uniformSize, inputsAligned16, hist_dev) && !lease.capturing()) {
+  if (outCapacity == 0xffffffffu && fusedEligible(B, uniformSize, inputsAligned16, hist_dev) && !lease.capturing()) {
     return encodeFused(arena, lease, stream, P, useChecksum, B, in, archives, floatType, uniformSize, checksumTemp,
                        outSize_dev);
   }
@@ -1237,6 +1244,7 @@ int encodeCommon(
     e.absentModulo = absentWorkgroupModulo();
     e.spill = spill;
     e.outSize = outSize_dev;
+    e.outCapacity = outCapacity;
     e.useChecksum = (useChecksum && floatType) ? 1 : 0;
     e.checksum = (useChecksum && floatType) ? checksumTemp : nullptr;
     int rc = launchEncode(P, floatType, e, tileBlocks, grid, stream);
@@ -1252,6 +1260,7 @@ int ansEncodeImpl(
     uint32_t* outSize_dev, hipStream_t stream) {
   DGPU_REQUIRE(validProbBits(P), "probBits must be 9, 10 or 11");
   DGPU_REQUIRE(B <= 65535u, "numInBatch must be <= 65535");
+  DGPU_REQUIRE(encodableSize(maxSize), "input larger than 1717538816 bytes: its maximum compressed size exceeds INT32_MAX (GpuANSEncode.cu:22)");
   if (tempUsed) *tempUsed = 0;
   if (B == 0) return DGPU_OK;
 
@@ -1293,6 +1302,7 @@ int floatCompressImpl(
   DGPU_REQUIRE(validProbBits(P), "probBits must be 9, 10 or 11");
   DGPU_REQUIRE(validFloatType(ft), "floatType must be float16, bfloat16 or float32");
   DGPU_REQUIRE(B <= 65535u, "numInBatch must be <= 65535");
+  DGPU_REQUIRE(encodableSize(maxSize), "tensor larger than 1717538816 words: the maximum compressed size of its exponent plane exceeds INT32_MAX (GpuANSEncode.cu:22)");
   if (tempUsed) *tempUsed = 0;
   if (B == 0) return DGPU_OK;
 
@@ -1402,7 +1412,7 @@ int decodeImpl(
     void* temp_dev, size_t tempBytes, size_t* tempUsed, uint32_t ft, int P, int useChecksum,
     uint32_t B, const HostParams* hp, const BatchView* strideIn, const BatchView* strideOut,
     uint32_t maxCapacity, uint8_t* outSuccess_dev, uint32_t* outSize_dev, hipStream_t stream,
-    int32_t* errBatch) {
+    int32_t* errBatch, uint32_t uniformInBytes = 0 /* stride batches: bytes available per archive (0 = unknown) */) {
   DGPU_REQUIRE(validProbBits(P), "probBits must be 9, 10 or 11");
   DGPU_REQUIRE(ft == 0 || validFloatType(ft), "bad floatType");
   DGPU_REQUIRE(B <= 65535u, "numInBatch must be <= 65535");
@@ -1458,6 +1468,7 @@ int decodeImpl(
     d.outSuccess = useChecksum ? successForChecksum : outSuccess_dev;
     d.outSize = useChecksum ? sizesForChecksum : outSize_dev;
     d.inBytes = inBytes_dev;
+    d.uniformInBytes = uniformInBytes;
     d.numInBatch = B;
     dim3 grid(maxTiles, B);
     int rc;
@@ -1627,7 +1638,10 @@ int dgpu_prof_summary(char* buf, size_t cap) {
 uint32_t dgpu_ans_max_compressed_size(uint32_t bytes) { return maxCompressedSizeHost(bytes); }
 
 uint32_t dgpu_float_max_compressed_size(uint32_t ft, uint32_t n) {
-  return 16u + maxCompressedSizeHost(n) + floatUncompDataSize(ft, n);
+  const uint32_t ans = maxCompressedSizeHost(n);
+  if (ans == 0u) return 0u;  // beyond the reference's INT32_MAX guard
+  const uint64_t total = 16ull + ans + (ft == kFloat32 ? 2ull * roundUp(n, 8u) + roundUp(n, 16u) : (uint64_t)roundUp(n, 16u));
+  return total > 0xffffffffull ? 0u : (uint32_t)total;
 }
 
 static size_t encodeTempBytes(uint32_t B, uint32_t maxBytes, uint32_t wordBytes, bool spills) {
@@ -1849,6 +1863,56 @@ int dgpu_float_decompress_split_size_bounded(
   DGPU_REQUIRE(validFloatType(floatType), "floatType must be float16, bfloat16 or float32");
   return decodeSplitCommon(temp_dev, tempBytes, tempUsed, floatType, probBits, useChecksum, numInBatch, in, out_dev,
                            outSplitSizes, outSuccess_dev, outSize_dev, stream, errBatch, inBytes);
+}
+
+// ---- float stride batches with capacities on both sides (the compressed collectives) --------------------
+int dgpu_float_compress_stride_capped(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, uint32_t floatType, int probBits, int useChecksum,
+    uint32_t numInBatch, const void* in_dev, uint32_t inWords, uint32_t inStrideBytes, void* out_dev,
+    uint32_t outStrideBytes, uint32_t outCapacityBytes, uint32_t* outSize_dev, void* stream) {
+  DGPU_REQUIRE(validProbBits(probBits), "probBits must be 9, 10 or 11");
+  DGPU_REQUIRE(validFloatType(floatType), "floatType must be float16, bfloat16 or float32");
+  DGPU_REQUIRE(numInBatch <= 65535u, "numInBatch must be <= 65535");
+  DGPU_REQUIRE(encodableSize(inWords), "tensor larger than 1717538816 words (GpuANSEncode.cu:22)");
+  const uint32_t wb = floatWordBytes(floatType);
+  DGPU_REQUIRE(((uintptr_t)in_dev % wb) == 0 && (numInBatch <= 1 || inStrideBytes % wb == 0), "float input must be float-word aligned");
+  DGPU_REQUIRE(((uintptr_t)out_dev % 16) == 0 && (numInBatch <= 1 || outStrideBytes % 16 == 0) && outCapacityBytes % 16 == 0,
+               "compressed output rows, their stride and their capacity must be 16-byte aligned");
+  DGPU_REQUIRE(numInBatch <= 1 || outCapacityBytes <= outStrideBytes, "outCapacityBytes must not exceed outStrideBytes");
+  DGPU_REQUIRE(inWords > kBlockSize, "capped compression needs rows of more than one 4096-word block");
+  // everything except the block data is stored unconditionally: it must fit
+  const uint32_t nb = divUp(inWords, kBlockSize);
+  const uint64_t fixed = (uint64_t)ansOffsetInArchive(floatType, inWords) + ansOverhead(nb);
+  DGPU_REQUIRE(fixed <= outCapacityBytes, "outCapacityBytes is smaller than the archive's header, tables and non-compressed planes");
+  if (tempUsed) *tempUsed = 0;
+  if (numInBatch == 0) return DGPU_OK;
+  hipStream_t st = (hipStream_t)stream;
+  StreamLease streamLease(st);
+  TempArena arena(temp_dev, tempBytes, streamLease);
+  const BatchView in = viewStride(in_dev, inStrideBytes, inWords);
+  const BatchView out = viewStride(out_dev, outStrideBytes, 0);
+  const bool aligned16 = ((uintptr_t)in_dev % 16) == 0 && (numInBatch <= 1 || inStrideBytes % 16 == 0);
+  int rc = encodeCommon(arena, streamLease, st, probBits, useChecksum != 0, numInBatch, in, out, floatType, inWords, inWords,
+                        aligned16, nullptr, outSize_dev, outCapacityBytes);
+  if (tempUsed) *tempUsed = arena.requested();
+  return rc;
+}
+
+int dgpu_float_decompress_stride_bounded(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, uint32_t floatType, int probBits, int useChecksum,
+    uint32_t numInBatch, const void* in_dev, uint32_t inStrideBytes, uint32_t inBytes, void* out_dev,
+    uint32_t outStrideBytes, uint32_t outCapacityWords, uint8_t* outSuccess_dev, uint32_t* outSize_dev, void* stream,
+    int32_t* errBatch) {
+  DGPU_REQUIRE(validFloatType(floatType), "floatType must be float16, bfloat16 or float32");
+  DGPU_REQUIRE(((uintptr_t)in_dev % 16) == 0 && (numInBatch <= 1 || inStrideBytes % 16 == 0),
+               "compressed input must be 16-byte aligned");
+  const uint32_t wb = floatWordBytes(floatType);
+  DGPU_REQUIRE(((uintptr_t)out_dev % wb) == 0 && (numInBatch <= 1 || outStrideBytes % wb == 0), "float output must be float-word aligned");
+  DGPU_REQUIRE(inBytes != 0, "inBytes must be the bytes available per compressed row");
+  BatchView in = viewStride(in_dev, inStrideBytes, 0);
+  BatchView out = viewStride(out_dev, outStrideBytes, outCapacityWords);
+  return decodeImpl(temp_dev, tempBytes, tempUsed, floatType, probBits, useChecksum, numInBatch, nullptr, &in, &out,
+                    outCapacityWords, outSuccess_dev, outSize_dev, (hipStream_t)stream, errBatch, inBytes);
 }
 
 // ---- info ------------------------------------------------------------------

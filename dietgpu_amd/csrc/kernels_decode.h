@@ -54,7 +54,11 @@ struct DecodeArgs {
   const uint32_t* inBytes; // [B] nullable: bytes available at in.ptr(b) (the *_bounded entry points); an archive
                            // that claims to be longer is rejected instead of being read past its buffer
   uint32_t numInBatch;     // B (k_ans_decode_pair; the general kernel takes it from the grid)
+  uint32_t uniformInBytes; // != 0 (and inBytes == nullptr): every archive has this many bytes available (stride batches)
 };
+__device__ __forceinline__ uint64_t decodeInBytes(const DecodeArgs& a, uint32_t b) {
+  return a.inBytes ? (uint64_t)a.inBytes[b] : (a.uniformInBytes ? (uint64_t)a.uniformInBytes : ~0ull);
+}
 
 // ---------------------------------------------------------------------------
 // Per-row sinks.  Each lane owns element row * 32 + hl of its block.  `e0` is
@@ -531,7 +535,7 @@ __global__ __launch_bounds__(decThreads(kTileBlocks)) void k_ans_decode(DecodeAr
 
   const uint8_t* archive = a.in.ptr(b);
   uint32_t floatSize = 0;
-  const uint64_t inBytes = a.inBytes ? (uint64_t)a.inBytes[b] : ~0ull;
+  const uint64_t inBytes = decodeInBytes(a, b);
   if (inBytes < (FT ? sizeof(FloatHeader) : sizeof(AnsHeader))) {  // uniform: not even a header
     if (tile == 0 && tid == 0) {
       if (a.outSuccess) a.outSuccess[b] = 0;

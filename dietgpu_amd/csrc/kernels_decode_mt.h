@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kWaves * 64u) __attribute__((amdgpu_waves_per_eu(8,
   const uint32_t slice = blockIdx.x;
 
   const uint8_t* archive = a.in.ptr(b);
-  const uint64_t inBytes = a.inBytes ? (uint64_t)a.inBytes[b] : ~0ull;
+  const uint64_t inBytes = decodeInBytes(a, b);
   if (inBytes < sizeof(AnsHeader)) {  // uniform: not even a header
     if (slice == 0 && tid == 0) {
       if (a.outSuccess) a.outSuccess[b] = 0;

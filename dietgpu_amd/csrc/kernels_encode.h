@@ -128,6 +128,9 @@ struct EncodeArgs {
   uint32_t absentModulo;     // test hook: workgroups with index % absentModulo == 1 start ~0.5 ms late (0 = off)
   uint16_t* spill;           // [gridDim.x][blocks per tile][encSpillSlotWords(P)] (kSpill kernels only)
   uint32_t* outSize;         // [B] nullable
+  uint32_t outCapacity;      // bytes the caller has at out.ptr(b): block data beyond it is NOT stored (outSize still
+                             // reports the full size); 0xffffffff = the reference's contract (room for the maximum).
+                             // The host guarantees that header, tables and non-compressed planes fit.
   uint32_t useChecksum;      // float header only
   const uint32_t* checksum;  // [B] nullable (float header only)
 };
@@ -948,16 +951,23 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
     DGPU_PHASE(4);
 
     if (haveBlock) {
-      uint4* dst = (uint4*)(ans + ansOverhead(nb) + 2u * (size_t)(sh->tileBase + sh->localOff[hw]));
+      const uint64_t dataOff = (uint64_t)ansOffsetInArchive(FT, size) + ansOverhead(nb) + 2ull * (sh->tileBase + sh->localOff[hw]);
+      uint4* dst = (uint4*)(archive + dataOff);
+      // 16-byte vectors of this block that still fit the caller's capacity (all of them under the reference's contract)
+      const uint64_t room = (uint64_t)a.outCapacity > dataOff ? ((uint64_t)a.outCapacity - dataOff) / 16u : 0u;
+      uint32_t fit = room > 0xffffffffull ? 0xffffffffu : (uint32_t)room;
       if (kSpill && spilled) {
         // spilled vectors first (written by this wave; its stores must have been performed)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint4* sp = (const uint4*)spillSlot;
-        const uint32_t sv = spilled / kBlockAlignWords;
-        for (uint32_t i = hl; i < sv; i += 32u) streamStore<DGPU_NT_ENC_STORES != 0>(&dst[i], sp[i]);
+        uint32_t sv = spilled / kBlockAlignWords;
+        const uint32_t svFit = sv < fit ? sv : fit;
+        for (uint32_t i = hl; i < svFit; i += 32u) streamStore<DGPU_NT_ENC_STORES != 0>(&dst[i], sp[i]);
         dst += sv;
+        fit -= svFit;
       }
-      const uint32_t vecs = roundUp(words, kBlockAlignWords) / kBlockAlignWords;
+      uint32_t vecs = roundUp(words, kBlockAlignWords) / kBlockAlignWords;
+      vecs = vecs < fit ? vecs : fit;
       const uint4* s4 = (const uint4*)stage;
       for (uint32_t i = hl; i < vecs; i += 32u) streamStore<DGPU_NT_ENC_STORES != 0>(&dst[i], s4[i]);
     }

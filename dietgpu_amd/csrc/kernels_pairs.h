@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64) void k_ans_decode_pair(DecodeArgs a) {
   uint64_t inBytes = ~0ull;
   if (live) {
     archive = a.in.ptr(b);
-    if (a.inBytes) inBytes = (uint64_t)a.inBytes[b];
+    inBytes = decodeInBytes(a, b);
     if (inBytes < (FT ? sizeof(FloatHeader) : sizeof(AnsHeader))) fail(0u);  // not even a header
   }
   if (FT && live) {

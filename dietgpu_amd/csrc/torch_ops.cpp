@@ -56,6 +56,20 @@ std::tuple<int64_t, int64_t> totalAndMaxSize(const std::vector<at::Tensor>& ts) 
   return {total, mx};
 }
 
+// the size queries return 0 beyond the reference's INT32_MAX guard (getMaxCompressedSize's CHECK_LE, GpuANSEncode.cu:22)
+uint32_t maxAnsSize(uint64_t bytes) {
+  TORCH_CHECK(bytes <= 0xffffffffull, "input of ", bytes, " bytes: sizes are 32-bit (GpuANSCodec.h)");
+  const uint32_t r = dgpu_ans_max_compressed_size((uint32_t)bytes);
+  TORCH_CHECK(r != 0, "input of ", bytes, " bytes: its maximum compressed size exceeds INT32_MAX (GpuANSEncode.cu:22)");
+  return r;
+}
+uint32_t maxFloatSize(uint32_t ft, uint64_t words) {
+  TORCH_CHECK(words <= 0xffffffffull, "tensor of ", words, " words: sizes are 32-bit (GpuFloatCodec.h)");
+  const uint32_t r = dgpu_float_max_compressed_size(ft, (uint32_t)words);
+  TORCH_CHECK(r != 0, "tensor of ", words, " words: the maximum compressed size exceeds INT32_MAX (GpuANSEncode.cu:22)");
+  return r;
+}
+
 void* streamOf(int dev) { return (void*)c10::hip::getCurrentHIPStream(dev).stream(); }
 
 void check(int rc, const char* what, bool isFloat) {
@@ -133,20 +147,20 @@ std::tuple<int64_t, int64_t> max_float_compressed_output_size(const std::vector<
   TORCH_CHECK(!ts.empty());
   auto sz = totalAndMaxSize(ts);
   return {(int64_t)ts.size(),
-          (int64_t)dgpu_float_max_compressed_size(floatTypeFromDtype(ts[0].scalar_type()), (uint32_t)std::get<1>(sz))};
+          (int64_t)maxFloatSize(floatTypeFromDtype(ts[0].scalar_type()), (uint64_t)std::get<1>(sz))};
 }
 
 int64_t max_float_compressed_size(const at::Tensor& dtype, int64_t size) {
-  return dgpu_float_max_compressed_size(floatTypeFromDtype(dtype.scalar_type()), (uint32_t)size);
+  return maxFloatSize(floatTypeFromDtype(dtype.scalar_type()), (uint64_t)size);
 }
 
 std::tuple<int64_t, int64_t> max_any_compressed_output_size(const std::vector<at::Tensor>& ts) {
   TORCH_CHECK(!ts.empty());
   auto sz = totalAndMaxSize(ts);
-  return {(int64_t)ts.size(), (int64_t)dgpu_ans_max_compressed_size((uint32_t)(std::get<1>(sz) * ts[0].element_size()))};
+  return {(int64_t)ts.size(), (int64_t)maxAnsSize((uint64_t)std::get<1>(sz) * ts[0].element_size())};
 }
 
-int64_t max_any_compressed_size(int64_t bytes) { return dgpu_ans_max_compressed_size((uint32_t)bytes); }
+int64_t max_any_compressed_size(int64_t bytes) { return maxAnsSize((uint64_t)bytes); }
 
 // ---- compress ------------------------------------------------------------------
 std::tuple<at::Tensor, at::Tensor, int64_t> compress_data(
@@ -224,7 +238,7 @@ std::tuple<std::vector<at::Tensor>, at::Tensor, int64_t> compress_data_split_siz
                   "All splits should start on a 16 byte boundary; the size of an interior split is not a multiple of 16 bytes");
     }
   }
-  int64_t maxCompressedBytes = compressAsFloat ? dgpu_float_max_compressed_size(ft, maxSize) : dgpu_ans_max_compressed_size(maxSize);
+  int64_t maxCompressedBytes = compressAsFloat ? maxFloatSize(ft, maxSize) : maxAnsSize(maxSize);
   at::Tensor comp, sizes;
   validateCompOut(outCompressed, outCompressedSizes, numInBatch, maxCompressedBytes, dev, tIn.device(), comp, sizes);
 

@@ -95,20 +95,26 @@ def _temp(temp_mem, dev):
 # ---------------------------------------------------------------- size queries
 def max_float_compressed_output_size(ts):
     _, mx = _total_and_max(ts)
-    return len(ts), int(lib().dgpu_float_max_compressed_size(_float_type(ts[0]), mx))
+    return len(ts), _guarded(int(lib().dgpu_float_max_compressed_size(_float_type(ts[0]), mx)), mx)
 
 
 def max_float_compressed_size(dtype, size):
-    return int(lib().dgpu_float_max_compressed_size(_float_type(dtype), size))
+    return _guarded(int(lib().dgpu_float_max_compressed_size(_float_type(dtype), size)), size)
 
 
 def max_any_compressed_output_size(ts):
     _, mx = _total_and_max(ts)
-    return len(ts), int(lib().dgpu_ans_max_compressed_size(mx * ts[0].element_size()))
+    return len(ts), _guarded(int(lib().dgpu_ans_max_compressed_size(mx * ts[0].element_size())), mx * ts[0].element_size())
 
 
 def max_any_compressed_size(nbytes):
-    return int(lib().dgpu_ans_max_compressed_size(nbytes))
+    return _guarded(int(lib().dgpu_ans_max_compressed_size(nbytes)), nbytes)
+
+
+def _guarded(size, n):
+    # 0 = beyond getMaxCompressedSize's CHECK_LE(rawSize, INT32_MAX) (GpuANSEncode.cu:22; upstream aborts)
+    _check(size != 0, f"input of {n} symbols: its maximum compressed size exceeds INT32_MAX (1717538816 is the largest)")
+    return size
 
 
 # -------------------------------------------------------------------- compress
@@ -180,8 +186,8 @@ def compress_data_split_size(compress_as_float, t_in, t_in_split_sizes, checksum
         if not compress_as_float and i != n - 1:
             _check(s % 4 == 0, "the size of an interior split is not a multiple of the alignment")
     mx = max(split)
-    cols = (int(lib().dgpu_float_max_compressed_size(ft, mx)) if compress_as_float
-            else int(lib().dgpu_ans_max_compressed_size(mx)))
+    cols = _guarded(int(lib().dgpu_float_max_compressed_size(ft, mx)) if compress_as_float
+                    else int(lib().dgpu_ans_max_compressed_size(mx)), mx)
     with torch.cuda.device(dev):
         comp, sizes = _validate_out(out_compressed, out_compressed_bytes, n, cols, dev, t_in.device)
         tp, tb = _temp(temp_mem, dev)

@@ -72,9 +72,12 @@ const char* dgpu_last_error(void);
 uint32_t dgpu_last_checksum_mismatches(int32_t* batchIdx, uint32_t* expected, uint32_t* got, uint32_t cap);
 
 /* ---- size queries -------------------------------------------------------- */
-/* getMaxCompressedSize, GpuANSCodec.h:22 / GpuANSEncode.cu:13-25 */
+/* getMaxCompressedSize, GpuANSCodec.h:22 / GpuANSEncode.cu:13-25.  Upstream CHECKs the result against INT32_MAX
+ * (GpuANSEncode.cu:22), i.e. aborts for inputs of more than 1 717 538 816 bytes; here such a size returns 0 (the
+ * C++ mirror aborts like upstream) and the encode entry points reject it with DGPU_ERR_INVALID_ARGUMENT. */
 uint32_t dgpu_ans_max_compressed_size(uint32_t uncompressedBytes);
-/* getMaxFloatCompressedSize, GpuFloatCodec.h:31 / GpuFloatCompress.cu:23-45 */
+/* getMaxFloatCompressedSize, GpuFloatCodec.h:31 / GpuFloatCompress.cu:23-45 (0 beyond the same guard, which
+ * applies to the exponent plane: numFloats bytes) */
 uint32_t dgpu_float_max_compressed_size(uint32_t floatType, uint32_t numFloats);
 /* Upper bound of temp memory the matching call needs, so a caller can size
  * `temp_dev` once and stay allocation-free (README.md:90-94). */
@@ -227,6 +230,24 @@ int dgpu_float_decompress_split_size_bounded(
     void* temp_dev, size_t tempBytes, size_t* tempUsed, uint32_t floatType, int probBits, int useChecksum,
     uint32_t numInBatch, const void* const* in, const uint32_t* inBytes,
     void* out_dev, const uint32_t* outSplitSizes,
+    uint8_t* outSuccess_dev, uint32_t* outSize_dev, void* stream, int32_t* errBatch);
+
+/* ---- float stride batches with capacities (no upstream equivalent) ---------------
+ * For exchanging compressed rows at a FIXED width (README.md:68-72,104: compressed collectives): the rows of one
+ * tensor are compressed straight into the rows of the send matrix, `outStrideBytes` apart, and nothing is stored
+ * beyond `outCapacityBytes` of a row -- a row whose archive is longer (outSize_dev[i] > outCapacityBytes) is
+ * incomplete and must be sent another way; outSize_dev reports the full size either way.  The capacity must hold
+ * everything but the block data (header, tables, non-compressed planes: DGPU_ERR_INVALID_ARGUMENT otherwise), rows
+ * have more than 4096 words.  The receiving side decodes rows of `inBytes` available bytes each; a row whose
+ * archive claims more is reported through outSuccess_dev and not read (as the *_bounded entry points above). */
+int dgpu_float_compress_stride_capped(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, uint32_t floatType, int probBits, int useChecksum,
+    uint32_t numInBatch, const void* in_dev, uint32_t inWords, uint32_t inStrideBytes,
+    void* out_dev, uint32_t outStrideBytes, uint32_t outCapacityBytes, uint32_t* outSize_dev, void* stream);
+int dgpu_float_decompress_stride_bounded(
+    void* temp_dev, size_t tempBytes, size_t* tempUsed, uint32_t floatType, int probBits, int useChecksum,
+    uint32_t numInBatch, const void* in_dev, uint32_t inStrideBytes, uint32_t inBytes,
+    void* out_dev, uint32_t outStrideBytes, uint32_t outCapacityWords,
     uint8_t* outSuccess_dev, uint32_t* outSize_dev, void* stream, int32_t* errBatch);
 
 /* floatGetCompressedInfo, GpuFloatCodec.h:264-277 / GpuFloatInfo.cu:17-45 */

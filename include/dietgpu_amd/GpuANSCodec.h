@@ -19,7 +19,14 @@ namespace dietgpu {
 constexpr int kANSRequiredAlignment = DGPU_ANS_REQUIRED_ALIGNMENT;
 constexpr int kANSDefaultProbBits = DGPU_ANS_DEFAULT_PROB_BITS;
 
-inline uint32_t getMaxCompressedSize(uint32_t uncompressedBytes) { return dgpu_ans_max_compressed_size(uncompressedBytes); }
+inline uint32_t getMaxCompressedSize(uint32_t uncompressedBytes) {
+  const uint32_t r = dgpu_ans_max_compressed_size(uncompressedBytes);
+  if (r == 0) {  // CHECK_LE(rawSize, INT32_MAX), GpuANSEncode.cu:22
+    fprintf(stderr, "getMaxCompressedSize(%u): exceeds INT32_MAX\n", uncompressedBytes);
+    abort();
+  }
+  return r;
+}
 
 struct ANSCodecConfig {
   inline ANSCodecConfig() : probBits(kANSDefaultProbBits), useChecksum(false) {}

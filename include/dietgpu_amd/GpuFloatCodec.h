@@ -10,7 +10,12 @@ namespace dietgpu {
 enum class FloatType : uint32_t { kUndefined = 0, kFloat16 = 1, kBFloat16 = 2, kFloat32 = 3 };
 
 inline uint32_t getMaxFloatCompressedSize(FloatType floatType, uint32_t size) {
-  return dgpu_float_max_compressed_size((uint32_t)floatType, size);
+  const uint32_t r = dgpu_float_max_compressed_size((uint32_t)floatType, size);
+  if (r == 0) {  // getMaxCompressedSize's CHECK_LE(rawSize, INT32_MAX), GpuANSEncode.cu:22
+    fprintf(stderr, "getMaxFloatCompressedSize(%u): exceeds INT32_MAX\n", size);
+    abort();
+  }
+  return r;
 }
 
 struct FloatCodecConfig {

@@ -14,6 +14,7 @@
 
 #include <pthread.h>
 #include <stdlib.h>
+#include <limits.h>
 #include <string.h>
 
 /* ---- constants: dietgpu/ans/GpuANSUtils.cuh:33-60 ---- */
@@ -60,6 +61,7 @@ uint32_t dgo_ans_max_compressed_size(uint32_t uncompressedBytes) {
   size_t raw = dgo_ans_compressed_overhead(K_BLOCK);
   raw += (size_t)raw_comp_block_max_size(K_BLOCK) * blocks;
   raw = (raw + 15u) / 16u * 16u;
+  if (raw > (size_t)INT32_MAX) return 0u; /* CHECK_LE(rawSize, INT32_MAX), GpuANSEncode.cu:22 (upstream aborts) */
   return (uint32_t)raw;
 }
 
@@ -78,6 +80,7 @@ uint32_t dgo_float_uncomp_data_size(uint32_t ft, uint32_t n) {
 
 /* getMaxFloatCompressedSize, GpuFloatCompress.cu:23-45 */
 uint32_t dgo_float_max_compressed_size(uint32_t ft, uint32_t n) {
+  if (dgo_ans_max_compressed_size(n) == 0u) return 0u;
   return 16u + dgo_ans_max_compressed_size(n) + dgo_float_uncomp_data_size(ft, n);
 }
 

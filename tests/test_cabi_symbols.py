@@ -37,6 +37,13 @@ def test_size_queries_match_oracle():
         assert L.dgpu_ans_max_compressed_size(n) == O.ans_max_compressed_size(n)
         for ft in (1, 2, 3):
             assert L.dgpu_float_max_compressed_size(ft, n) == O.float_max_compressed_size(ft, n)
+    # the reference CHECKs the maximum compressed size against INT32_MAX (GpuANSEncode.cu:22): 419 321 blocks are the
+    # largest input it accepts; beyond that the size queries return 0 (the C++ mirrors abort like upstream)
+    guard = 419321 * 4096
+    assert L.dgpu_ans_max_compressed_size(guard) == O.ans_max_compressed_size(guard) == 557600 + 5120 * 419321
+    assert L.dgpu_ans_max_compressed_size(guard) <= 2**31 - 1
+    assert L.dgpu_ans_max_compressed_size(guard + 1) == 0 == O.ans_max_compressed_size(guard + 1)
+    assert L.dgpu_float_max_compressed_size(2, guard + 1) == 0 and L.dgpu_float_max_compressed_size(2, 1 << 30) > (1 << 31)
     assert L.dgpu_ans_max_compressed_size(1 << 20) == 1868320
     assert L.dgpu_float_max_compressed_size(2, 524288) == 1737264
     # temp memory of the 256 x 1 MiB configs: ~10 MiB (partial histograms, tables, tile

@@ -21,11 +21,63 @@ DEV = "cuda:0"
 FT_DTYPE = {O.FLOAT16: torch.float16, O.BFLOAT16: torch.bfloat16, O.FLOAT32: torch.float32}
 
 
-@pytest.fixture(scope="module")
-def dg():
+class TorchOpsSurface:
+    """The same calls through torch.ops.dietgpu.* (csrc/torch_ops.cpp: the reference's op names and schemas,
+    DietGpu.cpp:915-937) -- the fast tensor surface.  The ops fix probBits at 10 (DietGpu.cpp:114): tests that ask
+    for another precision are skipped on this surface.  Everything else (lib(), size queries) is the package's."""
+
+    name = "torch_ops"
+
+    def __init__(self, pkg):
+        self._pkg = pkg
+        self.ops = pkg.load_torch_ops()
+
+    def __getattr__(self, attr):
+        return getattr(self._pkg, attr)
+
+    @staticmethod
+    def _p10(prob_bits):
+        if prob_bits != 10:
+            pytest.skip("torch.ops.dietgpu fixes probBits at 10 (DietGpu.cpp:114)")
+
+    def compress_data(self, as_float, ts, checksum=False, temp_mem=None, out_compressed=None, out_compressed_bytes=None, prob_bits=10):
+        self._p10(prob_bits)
+        return self.ops.compress_data(as_float, ts, checksum, temp_mem, out_compressed, out_compressed_bytes)
+
+    def decompress_data(self, as_float, ts_in, ts_out, checksum=False, temp_mem=None, out_status=None,
+                        out_decompressed_words=None, prob_bits=10):
+        self._p10(prob_bits)
+        return self.ops.decompress_data(as_float, ts_in, ts_out, checksum, temp_mem, out_status, out_decompressed_words)
+
+    def compress_data_split_size(self, as_float, t_in, splits, checksum=False, temp_mem=None, out_compressed=None,
+                                 out_compressed_bytes=None, prob_bits=10):
+        self._p10(prob_bits)
+        return self.ops.compress_data_split_size(as_float, t_in, splits, checksum, temp_mem, out_compressed, out_compressed_bytes)
+
+    def decompress_data_split_size(self, as_float, ts_in, t_out, splits, checksum=False, temp_mem=None, out_status=None,
+                                   out_decompressed_words=None, prob_bits=10):
+        self._p10(prob_bits)
+        return self.ops.decompress_data_split_size(as_float, ts_in, t_out, splits, checksum, temp_mem, out_status,
+                                                   out_decompressed_words)
+
+    def compress_data_simple(self, as_float, ts, checksum=False, prob_bits=10):
+        self._p10(prob_bits)
+        return self.ops.compress_data_simple(as_float, ts, checksum)
+
+    def decompress_data_simple(self, as_float, ts, checksum=False, prob_bits=10):
+        self._p10(prob_bits)
+        return self.ops.decompress_data_simple(as_float, ts, checksum)
+
+
+# Every test of this module (and of the modules that import the fixture) runs on BOTH tensor surfaces: the ctypes
+# mirror dietgpu_amd.ops and torch.ops.dietgpu.* -- the parity evidence is carried by the fast surface too.
+@pytest.fixture(scope="module", params=["ctypes", "torch_ops"])
+def dg(request):
     import dietgpu_amd
 
     dietgpu_amd.lib()  # fails loudly if the HIP extension is missing
+    if request.param == "torch_ops":
+        return TorchOpsSurface(dietgpu_amd)
     return dietgpu_amd
 
 
@@ -1406,3 +1458,46 @@ def test_checksum_mismatch_reports_every_member(dg, as_float):
     dietgpu_amd.load_torch_ops()
     with pytest.raises(RuntimeError, match="batch member 4:"):
         torch.ops.dietgpu.decompress_data(as_float, rows, outs, True, None, None, None)
+
+
+def test_one_gi_bf16_words_and_the_size_guard(dg):
+    # (a) the largest point of the reference's README plots: ONE tensor of 1024 Mi bf16 words (2 GiB; exponent plane
+    # 262 144 blocks = 32 768 encoder tiles), archive byte for byte against the oracle, round trip bit-exact.
+    n = 1 << 30
+    rng = np.random.default_rng(77)
+    # N(0,1) in bf16, built from a 64 Mi-word piece (host time) with per-piece exponent offsets so that the pieces differ
+    piece = (rng.standard_normal(1 << 26, dtype=np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    words = np.empty(n, np.uint16)
+    for k in range(n >> 26):
+        words[k << 26 : (k + 1) << 26] = piece + np.uint16((k % 5) << 7)
+    t = torch.from_numpy(words.view(np.int16)).to(DEV).view(torch.bfloat16)
+    comp, sizes, _ = dg.compress_data(True, [t])
+    got_n = int(sizes[0].item())
+    want = O.float_compress(O.BFLOAT16, words, 10)
+    assert got_n == want.size
+    got = comp[0, :got_n].cpu().numpy()
+    assert (got == want).all(), int(np.flatnonzero(got != want)[0])
+    out = torch.empty_like(t)
+    dg.decompress_data(True, [comp[0, :got_n]], [out])
+    assert torch.equal(out.view(torch.int16), t.view(torch.int16))
+    del comp, out, t, got, want
+    torch.cuda.empty_cache()
+
+    # (b) the reference's size guard (GpuANSEncode.cu:22): 419 321 blocks is the largest raw input; one byte more is
+    # rejected by the size query and by the encoder
+    guard = 419321 * 4096
+    L = dg.lib()
+    assert L.dgpu_ans_max_compressed_size(guard) == 557600 + 5120 * 419321 and L.dgpu_ans_max_compressed_size(guard + 1) == 0
+    x = np.tile((rng.zipf(1.3, 1 << 24) % 256).astype(np.uint8), guard // (1 << 24) + 1)[:guard]
+    tx = torch.from_numpy(x).to(DEV)
+    comp, sizes, _ = dg.compress_data(False, [tx])
+    k = int(sizes[0].item())
+    want = O.ans_encode(x, 10)
+    assert k == want.size and (comp[0, :k].cpu().numpy() == want).all()
+    outx = torch.empty_like(tx)
+    dg.decompress_data(False, [comp[0, :k]], [outx])
+    assert torch.equal(outx, tx)
+    del comp, outx
+    big = torch.zeros((guard + 4,), dtype=torch.uint8, device=DEV)
+    with pytest.raises(Exception, match="INT32_MAX|1717538816"):
+        dg.compress_data(False, [big])

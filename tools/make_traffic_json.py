@@ -4,14 +4,19 @@ profiles/<tag>_hbm_traffic.json (read by bench.py for roofline.traffic).
   tools/make_traffic_json.py <tag> <workload>=<pmc file> ...
 hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB: FETCH_SIZE counts half of the bytes of wide streaming reads on
 gfx950 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for every store shape the codec uses
-(profiles/r02_write_calib.txt)."""
+(profiles/r02_write_calib.txt).  The file is stamped with bench.kernel_source_hash(): bench.py reports
+`roofline.traffic` only when the stamp matches the sources of the build it runs."""
 import json
 import os
 import re
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash  # noqa: E402  (the stamp bench.py compares with the build it runs)
+
 tag = sys.argv[1]
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 3 --warmup 1`, "
+out = {"kernel_source_hash": kernel_source_hash(),
+       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 3 --warmup 1`, "
                  "mean per dispatch; tools/gpu_pmc.sh",
        "correction": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024",
        "workloads": {}}
