@@ -334,7 +334,7 @@ def run_collective(args, data, ft, desc, world, rank, device, D):
 
     def compressed():
         out, redo = plan.run(data)
-        return out, {"wire_bytes": plan.wire_bytes, "overflow_chunks": redo}
+        return out, dict(plan.last)
 
     def timed(fn):
         for _ in range(args.warmup):
@@ -366,7 +366,9 @@ def run_collective(args, data, ft, desc, world, rank, device, D):
             "steps": args.steps,
             "warmup": args.warmup,
             "config": {"workload": desc, "per_rank_bytes": raw_bytes, "chunks": args.chunks,
-                       "wire_bytes_per_rank": stats["wire_bytes"], "overflow_chunks": stats["overflow_chunks"]},
+                       "wire_bytes_per_rank": stats["wire_bytes"], "row_width_bytes": stats["width"],
+                       "largest_archive_bytes": stats["largest_archive"],
+                       "rows_sent_uncompressed": stats["rows_sent_uncompressed"]},
             "note": "world 1: the exchange is a local copy; the line then only shows the codec cost of the pipeline"
                     if world == 1 else "ring all-gather over xGMI is bound by one link per hop",
             "bit_exact": True,

@@ -208,7 +208,10 @@ def compressed_all_gather_pipelined(tensors, chunks=4, width_fraction=0.75, code
                 gp[r][:, :4].masked_fill_(over[r][:, None], 0)
                 rows = [gp[r][i] for i in range(hi - lo)]    # fixed-width rows; the archives say how long they are
                 outs = [torch.empty_like(t) for t in tensors[lo:hi]]
-                codec.decompress(rows, outs)
+                st = codec.decompress(rows, outs)
+                # any row that did not decode (cut off at the exchange width, or rejected for another reason) sends
+                # its chunk through the uncompressed fall-back: a failed decode never passes for a result
+                overflow_flags[-1] = overflow_flags[-1] | (st == 0).any().to(overflow_flags[-1].device)
                 gathered[r][lo:hi] = outs
     if on_gpu:
         cur.wait_stream(dec_stream)
@@ -242,116 +245,287 @@ class _NullContext:
 
 
 # ---------------------------------------------------------------------------
-# The same exchange as a reusable PLAN for a fixed shard shape (a training loop gathers the same
-# buffers every step): every buffer, pointer array and stream is created once, a step is K compress
-# calls, 2 K asynchronous collectives and K x world decompress calls straight on the C ABI -- no Python
-# lists of tensors, no per-step allocation (the generic function above spends milliseconds of host time
-# on 256-tensor lists, far more than the codec's 0.25 ms).
-class CompressedAllGatherPlan:
-    def __init__(self, shard, chunks=4, width_fraction=0.75, prob_bits=10):
+# The same exchanges as a reusable PLAN for a fixed shard shape (a training loop moves the same buffers every
+# step): every buffer and stream is created once; a step is K compress calls, K asynchronous collectives and
+# K x world decompress calls straight on the C ABI -- no Python lists of tensors, no per-step allocation, no copy
+# between the codec's output and the send buffer:
+#
+#   * rows travel at a fixed WIDTH (bytes).  The encoder writes every row straight into the send matrix at that
+#     stride and stores nothing beyond it (dgpu_float_compress_stride_capped); the decoder is told how many bytes
+#     a received row has and rejects a row whose archive claims more (dgpu_float_decompress_stride_bounded).  So a
+#     row that did not fit shows up as status 0 on every receiver -- no size exchange on the data path at all;
+#   * the width comes from the DATA: the first call probes (compresses its first chunk, one extra host sync, all
+#     ranks agree through an all-reduce MAX); every call folds the largest compressed row of all ranks into the ONE
+#     device-to-host read it ends with, and the next call uses that + 1/64 headroom.  Steady-state traffic has the
+#     same statistics step after step (activations, gradients), so fall-backs are rare -- and cheap:
+#   * fall-back is per ROW: rows with status 0 are gathered again uncompressed in one padded collective, the others
+#     are not touched;
+#   * all_gather(shard [n, elems]) -> [world, n, elems] and all_to_all(send [world, m, elems]) -> [world, m, elems]
+#     share all of this.
+# The codec is pluggable (compress rows into a strided matrix with a capacity, decompress rows with a bound), so the
+# world-2 logic runs on CPU under gloo with the oracle as codec (tests/test_sharding_gloo.py).
+class CAbiFloatCodec:
+    """The HIP float codec through the C ABI's capped / bounded stride entry points."""
+
+    def __init__(self, dtype, elems, max_rows, prob_bits=10, device=None):
         import ctypes as C
 
         from . import lib
         from .ops import _DTYPE_TO_FT
 
-        assert shard.is_cuda and shard.dim() == 2 and shard.is_contiguous()
         self.C, self.L = C, lib()
-        self.world = dist.get_world_size()
-        self.dev = shard.device
-        self.n, self.elems = shard.shape
-        self.dtype = shard.dtype
-        self.ft = _DTYPE_TO_FT[shard.dtype]
+        self.ft = _DTYPE_TO_FT[dtype]
         self.P = prob_bits
-        self.row_bytes = self.elems * shard.element_size()
-        self.cap = int(self.L.dgpu_float_max_compressed_size(self.ft, self.elems))
-        self.width = min((int(self.row_bytes * width_fraction) + 15) // 16 * 16, self.cap)
-        self.bounds = [shard_range(self.n, k, min(chunks, self.n)) for k in range(min(chunks, self.n))]
-        u8 = dict(dtype=torch.uint8, device=self.dev)
-        self.comp = torch.empty((self.n, self.cap), **u8)
-        self.payload = torch.empty((self.n, self.width), **u8)
-        self.sizes = torch.zeros((self.n,), dtype=torch.int32, device=self.dev)
-        self.out = torch.empty((self.world, self.n, self.elems), dtype=self.dtype, device=self.dev)
-        self.status = torch.zeros((self.world, self.n), **u8)
-        self.gp = [torch.empty((self.world, hi - lo, self.width), **u8) for lo, hi in self.bounds]
-        self.gs = [torch.empty((self.world, hi - lo), dtype=torch.int32, device=self.dev) for lo, hi in self.bounds]
-        self.overflow = torch.zeros((len(self.bounds),), dtype=torch.bool, device=self.dev)
-        tb = max(int(self.L.dgpu_float_compress_temp_bytes(self.ft, self.n, self.elems)),
-                 int(self.L.dgpu_float_decompress_temp_bytes(self.ft, self.n, self.elems, prob_bits)))
+        self.elems = elems
+        self.cap = int(self.L.dgpu_float_max_compressed_size(self.ft, elems))
+        self.elem_bytes = torch.empty((), dtype=dtype).element_size()
+        self.min_width = (16 + (elems + 15) // 16 * 16 * (3 if self.ft == 3 else 1) + 32 + 512 + 136 * ((elems + 4095) // 4096 + 1) + 15) // 16 * 16
+        tb = max(int(self.L.dgpu_float_compress_temp_bytes(self.ft, max_rows, elems)),
+                 int(self.L.dgpu_float_decompress_temp_bytes(self.ft, max_rows, elems, prob_bits)))
         # one temp region per stream: calls on different streams run concurrently
-        self.temp_c = torch.empty((tb,), **u8)
-        self.temp_d = torch.empty((tb,), **u8)
-        self.comp_stream = torch.cuda.Stream(self.dev)
-        self.dec_stream = torch.cuda.Stream(self.dev)
+        self.temp_c = torch.empty((tb,), dtype=torch.uint8, device=device)
+        self.temp_d = torch.empty((tb,), dtype=torch.uint8, device=device)
         self.err = C.c_int32(-1)
-        self._shard_ptr = None
 
-    def _arrays(self, shard):
-        C = self.C
-        if self._shard_ptr == shard.data_ptr():
-            return
-        self._shard_ptr = shard.data_ptr()
-        self.c_in, self.c_out, self.c_sz, self.d_in, self.d_out = [], [], [], [], []
-        for k, (lo, hi) in enumerate(self.bounds):
-            m = hi - lo
-            self.c_in.append((C.c_void_p * m)(*[shard.data_ptr() + (lo + i) * self.row_bytes for i in range(m)]))
-            self.c_out.append((C.c_void_p * m)(*[self.comp.data_ptr() + (lo + i) * self.cap for i in range(m)]))
-            self.c_sz.append((C.c_uint32 * m)(*([self.elems] * m)))
-            self.d_in.append([(C.c_void_p * m)(*[self.gp[k].data_ptr() + (r * m + i) * self.width for i in range(m)])
-                              for r in range(self.world)])
-            self.d_out.append([(C.c_void_p * m)(*[self.out.data_ptr() + ((r * self.n) + lo + i) * self.row_bytes
-                                                   for i in range(m)]) for r in range(self.world)])
+    def compress_into(self, rows, out, width, sizes, stream):
+        """rows [m, elems] (contiguous) -> out [m, width] (contiguous uint8), sizes [m] int32 = full archive sizes."""
+        C, L = self.C, self.L
+        m = rows.shape[0]
+        rc = L.dgpu_float_compress_stride_capped(
+            C.c_void_p(self.temp_c.data_ptr()), self.temp_c.numel(), None, self.ft, self.P, 0, m,
+            C.c_void_p(rows.data_ptr()), self.elems, self.elems * self.elem_bytes,
+            C.c_void_p(out.data_ptr()), width, width, C.c_void_p(sizes.data_ptr()), C.c_void_p(stream))
+        if rc:
+            raise RuntimeError(L.dgpu_last_error().decode())
+
+    def decompress_from(self, rows, width, out, status, stream):
+        """rows [m, width] -> out [m, elems]; status [m] uint8 = 0 for rows that are incomplete / not decodable."""
+        C, L = self.C, self.L
+        m = rows.shape[0]
+        rc = L.dgpu_float_decompress_stride_bounded(
+            C.c_void_p(self.temp_d.data_ptr()), self.temp_d.numel(), None, self.ft, self.P, 0, m,
+            C.c_void_p(rows.data_ptr()), width, width, C.c_void_p(out.data_ptr()), self.elems * self.elem_bytes,
+            self.elems, C.c_void_p(status.data_ptr()), None, C.c_void_p(stream), C.byref(self.err))
+        if rc:
+            raise RuntimeError(L.dgpu_last_error().decode())
+
+
+class CompressedExchangePlan:
+    """all_gather / all_to_all of float rows that moves compressed bytes.  See the comment block above."""
+
+    HEADROOM = 1.0 / 64.0
+
+    def __init__(self, dtype, elems, rows, chunks=4, prob_bits=10, device=None, codec=None, initial_width=None):
+        self.world = dist.get_world_size()
+        self.dev = torch.device(device) if device is not None else torch.device("cpu")
+        self.on_gpu = self.dev.type == "cuda"
+        self.dtype, self.elems, self.rows = dtype, elems, rows
+        self.row_bytes = elems * torch.empty((), dtype=dtype).element_size()
+        self.codec = codec or CAbiFloatCodec(dtype, elems, rows, prob_bits, self.dev)
+        self.cap = self.codec.cap
+        self.chunks = max(1, min(chunks, rows))
+        self.bounds = [shard_range(rows, k, self.chunks) for k in range(self.chunks)]
+        u8 = dict(dtype=torch.uint8, device=self.dev)
+        # send / receive matrices are flat and sized for the worst case; a step uses the first rows x width bytes
+        self.send = torch.empty((rows * self.cap,), **u8)
+        self.recv = torch.empty((self.world * rows * self.cap,), **u8)
+        self.sizes = torch.zeros((rows,), dtype=torch.int32, device=self.dev)
+        self.status = torch.zeros((self.world, rows), **u8)
+        self.stats = torch.zeros((2,), dtype=torch.int32, device=self.dev)  # {largest archive of all ranks, failed rows}
+        self.out = None
+        self.width = None if initial_width is None else self._round_width(initial_width)
+        self.comp_stream = torch.cuda.Stream(self.dev) if self.on_gpu else None
+        self.dec_stream = torch.cuda.Stream(self.dev) if self.on_gpu else None
+        self.last = {}
+
+    # ---- helpers
+    def _round_width(self, nbytes):
+        w = (int(nbytes) + 15) // 16 * 16
+        return max(min(w, self.cap), min(self.codec.min_width, self.cap))
+
+    def _stream_ptr(self, s):
+        return s.cuda_stream if s is not None else 0
+
+    def _on(self, s):
+        return torch.cuda.stream(s) if s is not None else _NullContext()
+
+    def _probe_width(self, rows2d):
+        """First call: compress the first chunk once, all ranks agree on max(size) -> width (one host sync)."""
+        lo, hi = self.bounds[0]
+        m = hi - lo
+        view = self.send[: m * self.cap].view(m, self.cap)
+        self.codec.compress_into(rows2d[lo:hi], view, self.cap, self.sizes[lo:hi], self._stream_ptr(torch.cuda.current_stream(self.dev) if self.on_gpu else None))
+        mx = self.sizes[lo:hi].max().to(torch.int32).reshape(1)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        self.width = self._round_width(int(mx.item()) * (1.0 + self.HEADROOM) + 64)
+
+    def _finish(self, kind, fallback):
+        """The ONE device-to-host read of a step: {largest archive over all ranks, rows that failed to decode}."""
+        self.stats[0] = self.sizes.max().to(torch.int32)
+        self.stats[1] = (self.status == 0).sum().to(torch.int32)
+        # MAX over ranks of both: every rank must agree on the next width AND on whether the fall-back (a collective)
+        # runs -- in the all-to-all only sender and receiver see a given row's status
+        dist.all_reduce(self.stats, op=dist.ReduceOp.MAX)
+        largest, failed = (int(v) for v in self.stats.tolist())
+        used_width = self.width
+        redo = fallback() if failed else 0
+        self.last = {"kind": kind, "width": used_width, "largest_archive": largest, "rows_sent_uncompressed": redo,
+                     "wire_bytes": self.rows * used_width + redo * self.row_bytes, "raw_bytes": self.rows * self.row_bytes}
+        # next step's width: what the data needed + headroom (it only moves when the data moves)
+        self.width = self._round_width(largest * (1.0 + self.HEADROOM) + 64)
+        return redo
+
+    # ---- all-gather
+    def all_gather(self, shard):
+        """shard [rows, elems] -> (gathered [world, rows, elems], rows that had to be sent uncompressed)."""
+        assert shard.shape == (self.rows, self.elems) and shard.dtype == self.dtype and shard.is_contiguous()
+        if self.out is None or self.out.shape[0] != self.world or self.out.dim() != 3:
+            self.out = torch.empty((self.world, self.rows, self.elems), dtype=self.dtype, device=self.dev)
+        if self.width is None:
+            self._probe_width(shard)
+        W, world = self.width, self.world
+        cur = torch.cuda.current_stream(self.dev) if self.on_gpu else None
+        if self.on_gpu:
+            self.comp_stream.wait_stream(cur)
+            self.dec_stream.wait_stream(cur)
+        works = []
+        with self._on(self.comp_stream):
+            for k, (lo, hi) in enumerate(self.bounds):
+                m = hi - lo
+                snd = self.send[lo * W : hi * W].view(m, W)
+                self.codec.compress_into(shard[lo:hi], snd, W, self.sizes[lo:hi], self._stream_ptr(self.comp_stream))
+                rcv = self.recv[world * lo * W : world * hi * W]
+                works.append(_all_gather_flat(rcv, snd.view(-1), world))
+        with self._on(self.dec_stream):
+            for k, (lo, hi) in enumerate(self.bounds):
+                m = hi - lo
+                if works[k] is not None:
+                    works[k].wait()
+                rcv = self.recv[world * lo * W : world * hi * W].view(world, m, W)
+                for r in range(world):
+                    self.codec.decompress_from(rcv[r], W, self.out[r, lo:hi], self.status[r, lo:hi], self._stream_ptr(self.dec_stream))
+        if self.on_gpu:
+            cur.wait_stream(self.comp_stream)
+            cur.wait_stream(self.dec_stream)
+
+        def fallback():
+            # per ROW: every rank knows every status (the same archives reached everybody); the rows that failed are
+            # gathered again uncompressed, padded to the largest count of any rank
+            bad = (self.status == 0)                                  # [world, rows]
+            counts = bad.sum(dim=1).tolist()
+            width = max(counts)
+            mine = bad[dist.get_rank()].nonzero().flatten()
+            pack = torch.zeros((width, self.elems), dtype=self.dtype, device=self.dev)
+            pack[: mine.numel()] = shard[mine]
+            got = torch.empty((world, width, self.elems), dtype=self.dtype, device=self.dev)
+            w = _all_gather_flat(got.view(-1), pack.view(-1), world)
+            if w is not None:
+                w.wait()
+            for r in range(world):
+                idx = bad[r].nonzero().flatten()
+                self.out[r, idx] = got[r, : idx.numel()]
+            return counts[dist.get_rank()]
+
+        redo = self._finish("all_gather", fallback)
+        return self.out, redo
+
+    # ---- all-to-all
+    def all_to_all(self, send):
+        """send [world, m, elems] (row block j goes to rank j) -> (received [world, m, elems] (block i came from rank i),
+        rows of this rank's receive side that had to be sent uncompressed)."""
+        world = self.world
+        assert send.dim() == 3 and send.shape[0] == world and send.shape[2] == self.elems and send.is_contiguous()
+        m = send.shape[1]
+        assert world * m == self.rows and send.dtype == self.dtype
+        if self.out is None or self.out.shape != send.shape:
+            self.out = torch.empty_like(send)
+        flat = send.view(world * m, self.elems)
+        if self.width is None:
+            self._probe_width(flat)
+        W = self.width
+        cur = torch.cuda.current_stream(self.dev) if self.on_gpu else None
+        if self.on_gpu:
+            self.comp_stream.wait_stream(cur)
+            self.dec_stream.wait_stream(cur)
+        # chunk k = rows [lo_k, hi_k) of EVERY destination block, so that each chunk is a complete all-to-all
+        cb = [shard_range(m, k, min(self.chunks, m)) for k in range(min(self.chunks, m))]
+        works = []
+        base = 0
+        with self._on(self.comp_stream):
+            for lo, hi in cb:
+                c = hi - lo
+                snd = self.send[base * W : (base + world * c) * W].view(world, c, W)
+                for j in range(world):
+                    self.codec.compress_into(send[j, lo:hi], snd[j], W, self.sizes[j * m + lo : j * m + hi], self._stream_ptr(self.comp_stream))
+                rcv = self.recv[base * W : (base + world * c) * W]
+                works.append((_all_to_all_flat(rcv, snd.view(-1), world), base, lo, hi))
+                base += world * c
+        st = self.status.view(-1)[: world * m].view(world, m)
+        with self._on(self.dec_stream):
+            for wk, b0, lo, hi in works:
+                c = hi - lo
+                if wk is not None:
+                    wk.wait()
+                rcv = self.recv[b0 * W : (b0 + world * c) * W].view(world, c, W)
+                for i in range(world):
+                    self.codec.decompress_from(rcv[i], W, self.out[i, lo:hi], st[i, lo:hi], self._stream_ptr(self.dec_stream))
+        if self.on_gpu:
+            cur.wait_stream(self.comp_stream)
+            cur.wait_stream(self.dec_stream)
+        if world * m < self.status.numel():
+            self.status.view(-1)[world * m :] = 1
+
+        def fallback():
+            # per ROW.  Only sender and receiver know which rows failed: the receiver tells every sender (a tiny
+            # all-gather of the status matrix), then the rows travel uncompressed in an all-to-all with uneven splits
+            mine = (st == 0).to(torch.uint8)                              # [src, m] as seen by me, the receiver
+            allst = torch.empty((world, world, m), dtype=torch.uint8, device=self.dev)
+            w0 = _all_gather_flat(allst.view(-1), mine.reshape(-1).contiguous(), world)
+            if w0 is not None:
+                w0.wait()
+            me = dist.get_rank()
+            bad_send = allst[:, me, :].bool()                             # [dst, m]: my rows that dst could not decode
+            bad_recv = mine.bool()                                        # [src, m]
+            in_split = bad_send.sum(dim=1).tolist()
+            out_split = bad_recv.sum(dim=1).tolist()
+            pack = send[bad_send]                                         # rows ordered by destination
+            got = torch.empty((sum(out_split), self.elems), dtype=self.dtype, device=self.dev)
+            dist.all_to_all_single(got, pack.contiguous(), out_split, in_split)
+            self.out[bad_recv] = got
+            return sum(out_split)
+
+        redo = self._finish("all_to_all", fallback)
+        return self.out, redo
+
+
+def _all_gather_flat(out_flat, in_flat, world):
+    """all-gather of flat byte / word tensors, asynchronous where the backend can (returns the work handle or None)."""
+    if dist.get_backend() == "gloo" or not in_flat.is_cuda:
+        parts = list(out_flat.view(world, -1).unbind(0))
+        dist.all_gather(parts, in_flat)
+        return None
+    return dist.all_gather_into_tensor(out_flat, in_flat, async_op=True)
+
+
+def _all_to_all_flat(out_flat, in_flat, world):
+    """all-to-all of equal flat slices (slice j of in_flat goes to rank j), asynchronous on RCCL."""
+    if not in_flat.is_cuda or dist.get_backend() == "gloo":
+        dist.all_to_all_single(out_flat, in_flat)
+        return None
+    return dist.all_to_all_single(out_flat, in_flat, async_op=True)
+
+
+class CompressedAllGatherPlan(CompressedExchangePlan):
+    """The all-gather of one [n, elems] shard (kept under its round-2 name; bench.py --collective)."""
+
+    def __init__(self, shard, chunks=4, prob_bits=10, initial_width=None, codec=None):
+        assert shard.dim() == 2 and shard.is_contiguous()
+        super().__init__(shard.dtype, shard.shape[1], shard.shape[0], chunks=chunks, prob_bits=prob_bits,
+                         device=shard.device, codec=codec, initial_width=initial_width)
 
     def run(self, shard):
-        """Returns (gathered [world, n, elems], number of chunks that had to be gathered uncompressed)."""
-        C, L = self.C, self.L
-        assert shard.shape == (self.n, self.elems) and shard.dtype == self.dtype and shard.is_contiguous()
-        self._arrays(shard)
-        cur = torch.cuda.current_stream(self.dev)
-        self.comp_stream.wait_stream(cur)
-        self.dec_stream.wait_stream(cur)
-        works = []
-        with torch.cuda.stream(self.comp_stream):
-            cs = C.c_void_p(self.comp_stream.cuda_stream)
-            for k, (lo, hi) in enumerate(self.bounds):
-                m = hi - lo
-                rc = L.dgpu_float_compress(C.c_void_p(self.temp_c.data_ptr()), self.temp_c.numel(), None, self.ft, self.P, 0,
-                                           m, self.c_in[k], self.c_sz[k], self.c_out[k],
-                                           C.c_void_p(self.sizes.data_ptr() + 4 * lo), cs)
-                if rc:
-                    raise RuntimeError(L.dgpu_last_error().decode())
-                self.payload[lo:hi].copy_(self.comp[lo:hi, : self.width])  # fixed-width rows for the exchange
-                wp = dist.all_gather_into_tensor(self.gp[k].view(self.world * m, self.width), self.payload[lo:hi], async_op=True)
-                ws = dist.all_gather_into_tensor(self.gs[k].view(-1), self.sizes[lo:hi], async_op=True)
-                works.append((wp, ws))
-        with torch.cuda.stream(self.dec_stream):
-            ds = C.c_void_p(self.dec_stream.cuda_stream)
-            for k, (lo, hi) in enumerate(self.bounds):
-                m = hi - lo
-                works[k][0].wait()
-                works[k][1].wait()
-                over = self.gs[k] > self.width                    # [world, m], on the device
-                self.overflow[k] = over.any()
-                # a row cut off at the exchange width must not be decoded (its block table points past the
-                # row): blank its header word so that the decoder rejects it -- still no host involvement
-                self.gp[k][:, :, :4].masked_fill_(over[:, :, None], 0)
-                for r in range(self.world):
-                    rc = L.dgpu_float_decompress(C.c_void_p(self.temp_d.data_ptr()), self.temp_d.numel(), None, self.ft, self.P, 0,
-                                                 m, self.d_in[k][r], self.d_out[k][r], self.c_sz[k],
-                                                 C.c_void_p(self.status.data_ptr() + r * self.n + lo), None, ds,
-                                                 C.byref(self.err))
-                    if rc:
-                        raise RuntimeError(L.dgpu_last_error().decode())
-        cur.wait_stream(self.comp_stream)
-        cur.wait_stream(self.dec_stream)
-        # the one host synchronisation: rows that did not fit the fixed width (incompressible data)
-        redo = [k for k, f in enumerate(self.overflow.tolist()) if f]
-        for k in redo:
-            lo, hi = self.bounds[k]
-            got = torch.empty((self.world, hi - lo, self.elems), dtype=self.dtype, device=self.dev)
-            dist.all_gather_into_tensor(got.view(self.world * (hi - lo), self.elems), shard[lo:hi])
-            self.out[:, lo:hi] = got
-        return self.out, len(redo)
+        return self.all_gather(shard)
 
     @property
     def wire_bytes(self):
-        return self.n * self.width
+        return self.last.get("wire_bytes", self.rows * (self.width or self.cap))

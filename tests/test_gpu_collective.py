@@ -63,25 +63,48 @@ def test_pipelined_compressed_all_gather_single_rank_rccl():
         assert stats["overflow_chunks"] == 0 and stats["wire_bytes"] <= 0.76 * stats["raw_bytes"]
         for a, b in zip(gathered[0], mine):
             assert torch.equal(a.view(torch.int16), b.view(torch.int16))
-        # the reusable plan (what bench.py --collective times): C ABI calls on prebuilt pointer arrays
+        # the reusable plan (what bench.py --collective times): the C ABI's capped / bounded stride entry points,
+        # rows compressed straight into the send matrix at a width taken from the data
         shard = torch.stack(mine)
         plan = D.CompressedAllGatherPlan(shard, chunks=3)
-        for _ in range(3):
+        for step in range(3):
             out, redo = plan.run(shard)
             torch.cuda.synchronize()
             assert redo == 0 and torch.equal(out[0].view(torch.int16), shard.view(torch.int16))
+            assert plan.last["width"] < 0.72 * shard.shape[1] * 2      # ~0.68 of the raw row + 1/64 headroom
+            assert plan.last["largest_archive"] <= plan.last["width"]
         assert bool(plan.status.all())
-        # incompressible rows do not fit the fixed width: detected on the device, gathered again uncompressed
-        noise = [torch.randint(-32768, 32767, (65536,), generator=g, dtype=torch.int16).to(dev).view(torch.bfloat16)
-                 for _ in range(5)]
+        # incompressible rows do not fit the width: exactly THOSE rows are gathered again uncompressed
+        noise = [torch.randint(-32768, 32767, (262144,), generator=g, dtype=torch.int16).to(dev).view(torch.bfloat16)
+                 for _ in range(2)]
+        mixed = torch.stack(mine[:5] + noise[:1] + mine[5:] + noise[1:])
+        plan2 = D.CompressedAllGatherPlan(mixed, chunks=2)
+        plan2.width = plan.width                                       # as if the previous steps had been compressible
+        out, redo = plan2.run(mixed)
+        torch.cuda.synchronize()
+        assert redo == 2 and torch.equal(out[0].view(torch.int16), mixed.view(torch.int16))
+        assert plan2.status.view(-1).tolist().count(0) == 2
+        out, redo = plan2.run(mixed)                                   # the width followed the data: nothing falls back
+        torch.cuda.synchronize()
+        assert redo == 0 and torch.equal(out[0].view(torch.int16), mixed.view(torch.int16))
         gathered, stats = D.compressed_all_gather_pipelined(noise, chunks=2)
         assert stats["overflow_chunks"] == 2
         for a, b in zip(gathered[0], noise):
             assert torch.equal(a.view(torch.int16), b.view(torch.int16))
-        nshard = torch.stack(noise)
-        out, redo = D.CompressedAllGatherPlan(nshard, chunks=2).run(nshard)
+        # BASELINE config 4 data (fp16, 50 % zeros, ratio 0.7498) must NOT fall back (round 2's fixed 0.75 did)
+        import refgen
+
+        sp = torch.from_numpy(refgen.sparse_fp16(8, 512 * 1024).view("int16")).to(dev).view(torch.float16)
+        plan4 = D.CompressedAllGatherPlan(sp, chunks=2, prob_bits=11)
+        for _ in range(2):
+            out, redo = plan4.run(sp)
+            torch.cuda.synchronize()
+            assert redo == 0 and torch.equal(out[0].view(torch.int16), sp.view(torch.int16))
+        # all-to-all on the same machinery (world 1: block 0 comes back)
+        plan5 = D.CompressedExchangePlan(torch.bfloat16, shard.shape[1], shard.shape[0], chunks=2, device=dev)
+        got, redo = plan5.all_to_all(shard.view(1, shard.shape[0], shard.shape[1]))
         torch.cuda.synchronize()
-        assert redo == 2 and torch.equal(out[0].view(torch.int16), nshard.view(torch.int16))
+        assert redo == 0 and torch.equal(got.view(torch.int16), shard.view(1, *shard.shape).view(torch.int16))
     finally:
         dist.destroy_process_group()
 
@@ -100,5 +123,5 @@ def test_bench_collective_mode_two_ranks_one_device():
                        capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["n_gpus"] == 2 and d["bit_exact"] and d["config"]["overflow_chunks"] == 0
+    assert d["n_gpus"] == 2 and d["bit_exact"] and d["config"]["rows_sent_uncompressed"] == 0
     assert d["config"]["wire_bytes_per_rank"] < d["config"]["per_rank_bytes"]

@@ -172,3 +172,103 @@ def test_compressed_all_gather_world2():
         # bf16 N(0,1): the wire carries fewer bytes than the raw tensors
         assert stats["payload_bytes"] < stats["raw_bytes"]
         assert stats["wire_bytes"] < stats["raw_bytes"]
+
+
+# ---------------------------------------------------------------- the exchange plan (all-gather + all-to-all)
+class _OracleStrideCodec:
+    """CPU stand-in for dietgpu_amd.distributed.CAbiFloatCodec (test infrastructure): rows are compressed by the
+    oracle into a strided matrix, nothing is stored beyond the capacity; a row whose archive claims more bytes than
+    the receiver has is rejected -- the contract of dgpu_float_compress_stride_capped / _decompress_stride_bounded."""
+
+    def __init__(self, O, elems):
+        self.O, self.elems = O, elems
+        self.cap = O.float_max_compressed_size(O.BFLOAT16, elems)
+        nb = (elems + 4095) // 4096
+        self.min_width = (16 + O.float_uncomp_data_size(O.BFLOAT16, elems) + O.ans_compressed_overhead(nb) + 31) // 16 * 16
+
+    def compress_into(self, rows, out, width, sizes, stream):
+        O = self.O
+        for i in range(rows.shape[0]):
+            a = O.float_compress(O.BFLOAT16, rows[i].view(torch.int16).numpy().view(np.uint16), 10)
+            k = min(a.size, width)
+            out[i, :k] = torch.from_numpy(a[:k].copy())
+            sizes[i] = a.size
+
+    def decompress_from(self, rows, width, out, status, stream):
+        O = self.O
+        for i in range(rows.shape[0]):
+            a = rows[i].numpy()
+            info = O.float_info(a)
+            if info["compressed"] > width:
+                status[i] = 0
+                continue
+            rc, w, _ = O.float_decompress(O.BFLOAT16, a[: info["compressed"]], 10, self.elems)
+            assert rc == 0
+            out[i].view(torch.int16).copy_(torch.from_numpy(w.view(np.int16).copy()))
+            status[i] = 1
+
+
+def _plan_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+
+    import oracle as O
+    from dietgpu_amd import distributed as D
+
+    D.init(backend="gloo")
+    elems, rows = 3 * 4096 + 40, 6
+    ok = True
+
+    def shard_of(r, step, noisy=()):
+        g = torch.Generator().manual_seed(1000 * step + r)
+        x = torch.randn(rows, elems, generator=g).to(torch.bfloat16)
+        for i in noisy:
+            x[i] = torch.randint(-32768, 32767, (elems,), generator=g, dtype=torch.int16).view(torch.bfloat16)
+        return x
+
+    plan = D.CompressedExchangePlan(torch.bfloat16, elems, rows, chunks=2, device="cpu", codec=_OracleStrideCodec(O, elems))
+    log = []
+    # step 0: the width is probed from the data; step 1: rank 1 has two incompressible rows -> exactly those go
+    # uncompressed; step 2: clean data again (the width has grown to the noisy rows' size: still no fall-back)
+    for step, noisy in ((0, {}), (1, {1: (2, 5)}), (2, {})):
+        mine = shard_of(rank, step, noisy.get(rank, ()))
+        out, redo = plan.all_gather(mine)
+        for r in range(world):
+            want = shard_of(r, step, noisy.get(r, ()))
+            ok = ok and torch.equal(out[r].view(torch.int16), want.view(torch.int16))
+        log.append((redo, plan.last["width"], plan.last["largest_archive"], plan.last["rows_sent_uncompressed"]))
+    ok = ok and log[0][0] == 0 and log[0][1] < int(0.72 * elems * 2)      # probed: ~0.68 of the raw row + headroom
+    ok = ok and log[1][0] == (2 if rank == 1 else 0)                       # per ROW, on the rank that owns them
+    ok = ok and log[2][0] == 0
+    # all-to-all on a second plan: block j of `send` goes to rank j
+    m = rows // world
+    plan2 = D.CompressedExchangePlan(torch.bfloat16, elems, rows, chunks=2, device="cpu", codec=_OracleStrideCodec(O, elems))
+    for step, noisy in ((0, {}), (1, {0: (4,)})):   # rank 0's row 4 = block 1, row 1: only rank 1 cannot decode it
+        mine = shard_of(rank, 10 + step, noisy.get(rank, ())).view(world, m, elems).contiguous()
+        got, redo = plan2.all_to_all(mine)
+        for src in range(world):
+            want = shard_of(src, 10 + step, noisy.get(src, ())).view(world, m, elems)[rank]
+            ok = ok and torch.equal(got[src].view(torch.int16), want.view(torch.int16))
+        log.append((redo, plan2.last["width"]))
+    ok = ok and log[3][0] == 0 and log[4][0] == (1 if rank == 1 else 0)
+    dist.barrier()
+    q.put((rank, ok, log))
+    dist.destroy_process_group()
+
+
+def test_exchange_plan_world2_all_gather_and_all_to_all():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_plan_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, log in res:
+        assert ok, (rank, log)
