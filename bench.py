@@ -156,13 +156,16 @@ class Codec:
         assert torch.equal(a, b), "round trip is not bit-exact"
 
 
-def kernel_profile(codec, steps):
+def kernel_profile(codec, steps, step_fn=None):
     """Second pass of the same steps with per-kernel HIP events on the launch stream."""
     L = codec.lib
     L.dgpu_prof_reset()
     L.dgpu_prof_enable(1)
-    for _ in range(steps):
-        codec.step()
+    for i in range(steps):
+        if step_fn:
+            step_fn(i)
+        else:
+            codec.step()
     torch.cuda.synchronize()
     L.dgpu_prof_enable(0)
     buf = C.create_string_buffer(1 << 16)
@@ -622,7 +625,7 @@ def main():
     # than the 256 MiB memory-side cache, so the decoder may find it there.  Here R distinct {input, archive,
     # output} sets (different data) are coded round robin -- with the default shape each set touches ~0.7 GB and
     # four of them 2.8 GB -- so neither an input nor an archive can still be cached when its turn comes again.
-    elapsed_rot, rot_sets, rot_bytes = None, 0, 0
+    elapsed_rot, rot_sets, rot_bytes, kernels_rot = None, 0, 0, None
     if args.rotate > 1:
         free_b = torch.cuda.mem_get_info(device)[0]
         per_set = codec.in_bytes * 2 + codec.comp.numel()
@@ -650,6 +653,9 @@ def main():
             elapsed_rot = D.max_over_ranks(elapsed_rot, device)
         for c2 in sets[1:]:
             c2.verify()
+        # per-kernel durations of the same rotation (HIP events around every launch)
+        prof_rot = kernel_profile(codec, max(args.steps, 100), lambda i: sets[i % rot_sets].step())
+        kernels_rot = {name: round(rec["total_ms"] / max(rec["launches"], 1) * 1e3, 2) for name, rec in prof_rot.items()}
         del sets
         for _ in range(args.warmup):
             codec.step()
@@ -723,6 +729,7 @@ def main():
             "ms_per_step_rotating": round(elapsed_rot / args.steps * 1e3, 4) if elapsed_rot else None,
             "rotating_sets": rot_sets,
             "rotating_footprint_bytes": rot_bytes,
+            "kernels_rotating_avg_us": kernels_rot,
             "step_frac_of_hbm_peak_rotating": (round(step_alg / (elapsed_rot / args.steps) / 1e9 / HBM_PEAK_GBPS, 4)
                                                if elapsed_rot else None),
             "ms_per_step_pointer_list": round(elapsed_ptrlist / args.steps * 1e3, 4),

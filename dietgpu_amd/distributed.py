@@ -331,7 +331,9 @@ class CompressedExchangePlan:
         self.recv = torch.empty((self.world * rows * self.cap,), **u8)
         self.sizes = torch.zeros((rows,), dtype=torch.int32, device=self.dev)
         self.status = torch.zeros((self.world, rows), **u8)
-        self.stats = torch.zeros((2,), dtype=torch.int32, device=self.dev)  # {largest archive of all ranks, failed rows}
+        self.stat_max = torch.zeros((1,), dtype=torch.int32, device=self.dev)   # largest archive of all ranks
+        self.stat_fail = torch.zeros((1,), dtype=torch.int32, device=self.dev)  # rows that failed to decode
+        self._max_work = None
         self.out = None
         self.width = None if initial_width is None else self._round_width(initial_width)
         self.comp_stream = torch.cuda.Stream(self.dev) if self.on_gpu else None
@@ -359,14 +361,23 @@ class CompressedExchangePlan:
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         self.width = self._round_width(int(mx.item()) * (1.0 + self.HEADROOM) + 64)
 
-    def _finish(self, kind, fallback):
+    def _post_compress(self):
+        """Right after the last compress call (on the compress stream): the largest archive of all ranks, as an
+        asynchronous all-reduce that overlaps with the exchange and the decompression."""
+        self.stat_max[0] = self.sizes.max()
+        self._max_work = dist.all_reduce(self.stat_max, op=dist.ReduceOp.MAX, async_op=True)
+
+    def _finish(self, kind, fallback, statuses_differ_between_ranks):
         """The ONE device-to-host read of a step: {largest archive over all ranks, rows that failed to decode}."""
-        self.stats[0] = self.sizes.max().to(torch.int32)
-        self.stats[1] = (self.status == 0).sum().to(torch.int32)
-        # MAX over ranks of both: every rank must agree on the next width AND on whether the fall-back (a collective)
-        # runs -- in the all-to-all only sender and receiver see a given row's status
-        dist.all_reduce(self.stats, op=dist.ReduceOp.MAX)
-        largest, failed = (int(v) for v in self.stats.tolist())
+        self.stat_fail[0] = (self.status == 0).sum()
+        if statuses_differ_between_ranks and self.world > 1:
+            # in the all-to-all only sender and receiver see a given row's status, and the fall-back is a collective:
+            # every rank must agree on whether it runs
+            dist.all_reduce(self.stat_fail, op=dist.ReduceOp.MAX)
+        if self._max_work is not None:
+            self._max_work.wait()
+            self._max_work = None
+        largest, failed = (int(v) for v in torch.cat([self.stat_max, self.stat_fail]).tolist())
         used_width = self.width
         redo = fallback() if failed else 0
         self.last = {"kind": kind, "width": used_width, "largest_archive": largest, "rows_sent_uncompressed": redo,
@@ -396,6 +407,7 @@ class CompressedExchangePlan:
                 self.codec.compress_into(shard[lo:hi], snd, W, self.sizes[lo:hi], self._stream_ptr(self.comp_stream))
                 rcv = self.recv[world * lo * W : world * hi * W]
                 works.append(_all_gather_flat(rcv, snd.view(-1), world))
+            self._post_compress()
         with self._on(self.dec_stream):
             for k, (lo, hi) in enumerate(self.bounds):
                 m = hi - lo
@@ -426,7 +438,7 @@ class CompressedExchangePlan:
                 self.out[r, idx] = got[r, : idx.numel()]
             return counts[dist.get_rank()]
 
-        redo = self._finish("all_gather", fallback)
+        redo = self._finish("all_gather", fallback, False)  # every rank decoded the same archives
         return self.out, redo
 
     # ---- all-to-all
@@ -460,6 +472,7 @@ class CompressedExchangePlan:
                 rcv = self.recv[base * W : (base + world * c) * W]
                 works.append((_all_to_all_flat(rcv, snd.view(-1), world), base, lo, hi))
                 base += world * c
+            self._post_compress()
         st = self.status.view(-1)[: world * m].view(world, m)
         with self._on(self.dec_stream):
             for wk, b0, lo, hi in works:
@@ -494,7 +507,7 @@ class CompressedExchangePlan:
             self.out[bad_recv] = got
             return sum(out_split)
 
-        redo = self._finish("all_to_all", fallback)
+        redo = self._finish("all_to_all", fallback, True)
         return self.out, redo
 
 
