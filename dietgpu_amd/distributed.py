@@ -331,8 +331,7 @@ class CompressedExchangePlan:
         self.recv = torch.empty((self.world * rows * self.cap,), **u8)
         self.sizes = torch.zeros((rows,), dtype=torch.int32, device=self.dev)
         self.status = torch.zeros((self.world, rows), **u8)
-        self.stat_max = torch.zeros((1,), dtype=torch.int32, device=self.dev)   # largest archive of all ranks
-        self.stat_fail = torch.zeros((1,), dtype=torch.int32, device=self.dev)  # rows that failed to decode
+        self.stat = torch.zeros((2,), dtype=torch.int32, device=self.dev)  # {largest archive of all ranks, rows decoded}
         self._max_work = None
         self.out = None
         self.width = None if initial_width is None else self._round_width(initial_width)
@@ -364,20 +363,21 @@ class CompressedExchangePlan:
     def _post_compress(self):
         """Right after the last compress call (on the compress stream): the largest archive of all ranks, as an
         asynchronous all-reduce that overlaps with the exchange and the decompression."""
-        self.stat_max[0] = self.sizes.max()
-        self._max_work = dist.all_reduce(self.stat_max, op=dist.ReduceOp.MAX, async_op=True)
+        torch.amax(self.sizes, dim=0, keepdim=True, out=self.stat[0:1])
+        self._max_work = dist.all_reduce(self.stat[0:1], op=dist.ReduceOp.MAX, async_op=True) if self.world > 1 else None
 
     def _finish(self, kind, fallback, statuses_differ_between_ranks):
-        """The ONE device-to-host read of a step: {largest archive over all ranks, rows that failed to decode}."""
-        self.stat_fail[0] = (self.status == 0).sum()
+        """The ONE device-to-host read of a step: {largest archive over all ranks, rows that decoded}."""
+        torch.sum(self.status.view(-1), dim=0, keepdim=True, dtype=torch.int32, out=self.stat[1:2])
         if statuses_differ_between_ranks and self.world > 1:
             # in the all-to-all only sender and receiver see a given row's status, and the fall-back is a collective:
             # every rank must agree on whether it runs
-            dist.all_reduce(self.stat_fail, op=dist.ReduceOp.MAX)
+            dist.all_reduce(self.stat[1:2], op=dist.ReduceOp.MIN)
         if self._max_work is not None:
             self._max_work.wait()
             self._max_work = None
-        largest, failed = (int(v) for v in torch.cat([self.stat_max, self.stat_fail]).tolist())
+        largest, decoded = (int(v) for v in self.stat.tolist())
+        failed = self.status.numel() - decoded
         used_width = self.width
         redo = fallback() if failed else 0
         self.last = {"kind": kind, "width": used_width, "largest_archive": largest, "rows_sent_uncompressed": redo,

@@ -52,8 +52,8 @@ def timed(name, fn, reps=200):
 timed("compress_into (256 rows, capped)", lambda: codec.compress_into(shard, snd, W, plan.sizes, cs))
 timed("all_gather_into_tensor (184 MB, 1 rank)", lambda: dist.all_gather_into_tensor(rcv, snd.view(-1)))
 timed("decompress_from (256 rows, bounded)", lambda: codec.decompress_from(rcv.view(256, W), W, plan.out[0], plan.status[0], cs))
-timed("stats ops (max + async all_reduce, count)", lambda: (plan._post_compress(), plan.stat_fail.__setitem__(0, (plan.status == 0).sum()), plan._max_work.wait()))
+timed("stats ops (max + async all_reduce, count)", lambda: (plan._post_compress(), torch.sum(plan.status.view(-1), dim=0, keepdim=True, dtype=torch.int32, out=plan.stat[1:2])))
                                                       
-timed("stats.tolist() (device-to-host + sync)", lambda: torch.cat([plan.stat_max, plan.stat_fail]).tolist())
+timed("stats.tolist() (device-to-host + sync)", lambda: plan.stat.tolist())
 timed("plain all_gather_into_tensor of the raw shard", lambda: dist.all_gather_into_tensor(plan.out.view(-1), shard.view(-1)))
 dist.destroy_process_group()
