@@ -19,12 +19,18 @@
 
 // Streaming (non-temporal) access helpers.  kNt selects the cache policy at the
 // call site; the DGPU_NT_* macros are the A/B knobs the defaults were chosen with
-// ("cache policy"):
-//   * decoded float words are written once and not read again by the codec: if
-//     they are left dirty in the 256 MiB memory-side cache, the NEXT kernel pays
-//     for their write-back (the histogram pass ran at 3.5 TB/s instead of 5.5)
-//   * the encoder's and the histogram's input reads are one-shot streams that
-//     would only evict the archive being written
+// ("cache policy"; round 3 judged them on ROTATING buffers -- inputs, archives and outputs that
+// are not in the 256 MiB memory-side cache when their turn comes, as in real use -- not on a loop that re-codes
+// one buffer set):
+//   * decoded float words are written once and not read again by the codec: non-temporal stores
+//   * the encoder's input reads are a one-shot stream: non-temporal loads
+//   * the histogram pass of 16-BIT FLOAT inputs reads with ORDINARY loads (DGPU_NT_HIST_LOADS_F16 = 0): they
+//     allocate in the memory-side cache and thereby push out the dirty lines the previous kernels left there (the
+//     decoder's output) while this read-only kernel has write bandwidth to spare -- the histogram takes 64 instead
+//     of 46 us, the decoder that follows 80 instead of 117 (it no longer waits for write-backs to make room for
+//     its own stores), and the encoder's read of the same words hits the cache: 256 x 512 Ki bf16 0.2515 -> 0.228 ms
+//     per step on rotating buffers, fp16 0.256 -> 0.234 (profiles/r03_ab_cache_policy_rotating*.txt).  Raw bytes
+//     and fp32 lose with it (+3 % / +13 %) and keep non-temporal histogram loads.
 //   * archive stores stay cacheable: the consumer (decode, a send) follows soon
 #ifndef DGPU_NT_DEC_STORES
 #define DGPU_NT_DEC_STORES 1
@@ -34,6 +40,9 @@
 #endif
 #ifndef DGPU_NT_HIST_LOADS
 #define DGPU_NT_HIST_LOADS 1
+#endif
+#ifndef DGPU_NT_HIST_LOADS_F16
+#define DGPU_NT_HIST_LOADS_F16 0
 #endif
 #ifndef DGPU_NT_ENC_LOADS
 #define DGPU_NT_ENC_LOADS 1
@@ -78,6 +87,10 @@ constexpr uint32_t kFloatVersion = 0x0001u;
 constexpr uint32_t kBlockAlignWords = 8;   // 16 bytes of u16
 
 constexpr uint32_t kFloat16 = 1, kBFloat16 = 2, kFloat32 = 3;
+// cache policy of the histogram pass's input loads, by input type (see the top of this file)
+__host__ __device__ constexpr bool histLoadsNonTemporal(uint32_t ft) {
+  return (ft == kFloat16 || ft == kBFloat16) ? (DGPU_NT_HIST_LOADS_F16 != 0) : (DGPU_NT_HIST_LOADS != 0);
+}
 
 // Blocks handled by one 256-thread workgroup: 4 wave64 x 2 half-waves.
 constexpr uint32_t kBlocksPerTile = 8;

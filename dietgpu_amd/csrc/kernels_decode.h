@@ -76,6 +76,20 @@ __device__ __forceinline__ uint64_t decodeInBytes(const DecodeArgs& a, uint32_t 
 #ifndef DGPU_DEC_WIDE_STORES
 #define DGPU_DEC_WIDE_STORES 1
 #endif
+// DGPU_NT_DEC_LOADS: the decoder's reads of the archive (non-compressed bytes, compressed words) as non-temporal
+// (streaming) loads -- an A/B knob of the cache-policy study (rotating buffers)
+#ifndef DGPU_NT_DEC_LOADS
+#define DGPU_NT_DEC_LOADS 0
+#endif
+__device__ __forceinline__ uint2 decLoad8(const uint8_t* p) {
+  typedef uint32_t u32x2n __attribute__((ext_vector_type(2)));
+  if (DGPU_NT_DEC_LOADS) {
+    const u32x2n v = __builtin_nontemporal_load((const u32x2n*)p);
+    return make_uint2(v.x, v.y);
+  }
+  return *(const uint2*)p;
+}
+__device__ __forceinline__ uint4 decLoad16(const uint8_t* p) { return streamLoad<DGPU_NT_DEC_LOADS != 0>((const uint4*)p); }
 typedef __attribute__((address_space(3))) uint16_t LdsU16w;
 typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4w LdsU4w;
@@ -139,7 +153,7 @@ struct RowSink<kFloat16> {  // word = comp << 8 | nonComp
   // wide variant (see decodeBlock): rows stage {sym, 0}; a lane joins its 8 consecutive words with the 8
   // non-compressed bytes it loaded with ONE 8-byte load: one v_perm_b32 per pair of words
   static constexpr uint32_t kXposeBytes = 512;
-  __device__ __forceinline__ uint2 prefetchGroup(uint32_t g, uint32_t hl) const { return *(const uint2*)(nc - hl + g * 256u + hl * 8u); }
+  __device__ __forceinline__ uint2 prefetchGroup(uint32_t g, uint32_t hl) const { return decLoad8(nc - hl + g * 256u + hl * 8u); }
   __device__ __forceinline__ void stageRow(uint32_t xpose, uint32_t j, uint32_t hl, uint32_t e0) const {
     *(LdsU16w*)(uintptr_t)(xpose + (j * 32u + hl) * 2u) = (uint16_t)(e0 >> 16);
   }
@@ -174,7 +188,7 @@ struct RowSink<kBFloat16> {  // word = (comp << 8 | nonComp) >> 1 | (nonComp & 1
   // wide variant: as fp16, then every 16-bit half {exp, nc} rotated right by one (sign to the top):
   // (h >> 1) + h * 2^15 on packed halves (v_pk_lshrrev_b16 + v_pk_mad_u16)
   static constexpr uint32_t kXposeBytes = 512;
-  __device__ __forceinline__ uint2 prefetchGroup(uint32_t g, uint32_t hl) const { return *(const uint2*)(nc - hl + g * 256u + hl * 8u); }
+  __device__ __forceinline__ uint2 prefetchGroup(uint32_t g, uint32_t hl) const { return decLoad8(nc - hl + g * 256u + hl * 8u); }
   __device__ __forceinline__ void stageRow(uint32_t xpose, uint32_t j, uint32_t hl, uint32_t e0) const {
     *(LdsU16w*)(uintptr_t)(xpose + (j * 32u + hl) * 2u) = (uint16_t)(e0 >> 16);
   }
@@ -347,7 +361,7 @@ __device__ __forceinline__ void decodeBlock(
     for (uint32_t k = 0; k < 4u; ++k) {
       const uint32_t off = (k * 32u + hl) * 16u;
       v[k] = make_uint4(0, 0, 0, 0);
-      if (off < paddedBytes) v[k] = *(const uint4*)(gwords + off);
+      if (off < paddedBytes) v[k] = decLoad16(gwords + off);
     }
 #pragma unroll
     for (uint32_t k = 0; k < 4u; ++k) {
@@ -361,7 +375,7 @@ __device__ __forceinline__ void decodeBlock(
       --lowChunk;
       const uint32_t off = (uint32_t)lowChunk * 512u + hl * 16u;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (off < paddedBytes) v = *(const uint4*)(gwords + off);
+      if (off < paddedBytes) v = decLoad16(gwords + off);
       *(LdsU4*)(uintptr_t)(ringBase | (((uint32_t)lowChunk & 3u) * 512u + hl * 16u)) = u32x4{v.x, v.y, v.z, v.w};
     }
   }
@@ -483,7 +497,7 @@ __device__ __forceinline__ void decodeBlock(
       if (lowChunk > 0 && (uint32_t)lowChunk * kRingChunkWords + 512u > posw) {
         --lowChunk;
         const uint32_t off = (uint32_t)lowChunk * 512u + hl * 16u;
-        pending = (off < paddedBytes) ? *(const uint4*)(gwords + off) : make_uint4(0, 0, 0, 0);
+        pending = (off < paddedBytes) ? decLoad16(gwords + off) : make_uint4(0, 0, 0, 0);
         pendingChunk = lowChunk;
       }
     }
