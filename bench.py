@@ -625,7 +625,7 @@ def main():
     # than the 256 MiB memory-side cache, so the decoder may find it there.  Here R distinct {input, archive,
     # output} sets (different data) are coded round robin -- with the default shape each set touches ~0.7 GB and
     # four of them 2.8 GB -- so neither an input nor an archive can still be cached when its turn comes again.
-    elapsed_rot, rot_sets, rot_bytes, kernels_rot = None, 0, 0, None
+    elapsed_rot, rot_sets, rot_bytes, kernels_rot, rot_extra = None, 0, 0, None, {}
     if args.rotate > 1:
         free_b = torch.cuda.mem_get_info(device)[0]
         per_set = codec.in_bytes * 2 + codec.comp.numel()
@@ -656,6 +656,29 @@ def main():
         # per-kernel durations of the same rotation (HIP events around every launch)
         prof_rot = kernel_profile(codec, max(args.steps, 100), lambda i: sets[i % rot_sets].step())
         kernels_rot = {name: round(rec["total_ms"] / max(rec["launches"], 1) * 1e3, 2) for name, rec in prof_rot.items()}
+
+        def rotate(fn):
+            for i in range(args.warmup):
+                fn(sets[i % rot_sets])
+            fence()
+            t_ = time.perf_counter()
+            for i in range(args.steps):
+                fn(sets[i % rot_sets])
+            fence()
+            e_ = time.perf_counter() - t_
+            return (D.max_over_ranks(e_, device) if distributed else e_) / args.steps * 1e3
+
+        # The round trip still lets the decoder find the archive its encoder has just written in the memory-side
+        # cache.  The two directions ALONE on rotating buffers -- a sender that only compresses, a receiver that only
+        # decompresses -- share nothing:
+        rot_extra["ms_compress_only_rotating"] = round(rotate(lambda c: c.encode()), 4)
+        rot_extra["ms_decompress_only_rotating"] = round(rotate(lambda c: c.decode()), 4)
+        # ... and the round trip with the histogram pass reading through the cache (dgpu_set_histogram_load_policy(1)):
+        # best for exactly this loop, not the default because it loses wherever only one direction runs
+        codec.lib.dgpu_set_histogram_load_policy(1)
+        rot_extra["ms_per_step_rotating_cached_histogram_loads"] = round(rotate(lambda c: c.step()), 4)
+        rot_extra["ms_compress_only_rotating_cached_histogram_loads"] = round(rotate(lambda c: c.encode()), 4)
+        codec.lib.dgpu_set_histogram_load_policy(-1)
         del sets
         for _ in range(args.warmup):
             codec.step()
@@ -730,6 +753,7 @@ def main():
             "rotating_sets": rot_sets,
             "rotating_footprint_bytes": rot_bytes,
             "kernels_rotating_avg_us": kernels_rot,
+            **rot_extra,
             "step_frac_of_hbm_peak_rotating": (round(step_alg / (elapsed_rot / args.steps) / 1e9 / HBM_PEAK_GBPS, 4)
                                                if elapsed_rot else None),
             "ms_per_step_pointer_list": round(elapsed_ptrlist / args.steps * 1e3, 4),

@@ -53,6 +53,7 @@ _SIGS = {
     "dgpu_debug_set_param_cache": (None, [i32]),
     "dgpu_debug_set_fused": (None, [i32]),
     "dgpu_has_fused": (i32, []),
+    "dgpu_set_histogram_load_policy": (None, [i32]),
     "dgpu_release_graph_state": (i32, []),
 }
 

@@ -1111,6 +1111,15 @@ int encodeFused(
 
 #endif
 
+// Cache policy of the histogram pass's input loads (format.h): non-temporal by default; ordinary (allocating) loads
+// on request (dgpu_set_histogram_load_policy) for pipelines in which the codec's own dirty lines are what fills the
+// memory-side cache when the pass starts.
+std::atomic<int> g_histLoadPolicy{-1};  // -1: the compile-time default per input type, 0: non-temporal, 1: ordinary
+bool histogramLoadsNonTemporal(uint32_t ft) {
+  const int m = g_histLoadPolicy.load();
+  return m < 0 ? histLoadsNonTemporal(ft) : m == 0;
+}
+
 // Shared tail of every encode entry point: [checksum] -> histogram (+ fused
 // normalisation) -> encode.  `in` holds raw bytes (floatType == 0: the ANS
 // archive is the whole output) or float words (floatType != 0: the encoder
@@ -1194,20 +1203,26 @@ int encodeCommon(
     fuse.norm = n;
     // bins with 32 lane slots unless a workgroup sees too little data to pay for zeroing / folding them
     const bool smallBins = (uint64_t)maxSize * wordBytes / grid.x <= 64u * 1024u;
-#define DGPU_HIST_LAUNCH(S)                                                                                       \
+#define DGPU_HIST_LAUNCH_NT(S, NT)                                                                                \
     switch (floatType) {                                                                                          \
       case 0:                                                                                                     \
-        DGPU_LAUNCH("k_histogram", stream, (k_histogram<S>), grid, dim3(256), 0, stream, in, histTemp, 1u, fuse); \
+        DGPU_LAUNCH("k_histogram", stream, (k_histogram<S, NT>), grid, dim3(256), 0, stream, in, histTemp, 1u, fuse); \
         break;                                                                                                    \
       case kFloat16:                                                                                              \
-        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kFloat16, S>), grid, dim3(256), 0, stream, in, histTemp, 1u, fuse); \
+        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kFloat16, S, NT>), grid, dim3(256), 0, stream, in, histTemp, 1u, fuse); \
         break;                                                                                                    \
       case kBFloat16:                                                                                             \
-        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kBFloat16, S>), grid, dim3(256), 0, stream, in, histTemp, 1u, fuse); \
+        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kBFloat16, S, NT>), grid, dim3(256), 0, stream, in, histTemp, 1u, fuse); \
         break;                                                                                                    \
       default:                                                                                                    \
-        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kFloat32, S>), grid, dim3(256), 0, stream, in, histTemp, 1u, fuse); \
+        DGPU_LAUNCH("k_float_histogram", stream, (k_float_histogram<kFloat32, S, NT>), grid, dim3(256), 0, stream, in, histTemp, 1u, fuse); \
         break;                                                                                                    \
+    }
+#define DGPU_HIST_LAUNCH(S)                 \
+    if (histogramLoadsNonTemporal(floatType)) { \
+      DGPU_HIST_LAUNCH_NT(S, true)          \
+    } else {                                \
+      DGPU_HIST_LAUNCH_NT(S, false)         \
     }
     if (smallBins) {
       DGPU_HIST_LAUNCH(kHistSlotsSmall)
@@ -1215,6 +1230,7 @@ int encodeCommon(
       DGPU_HIST_LAUNCH(kHistSlotsLarge)
     }
 #undef DGPU_HIST_LAUNCH
+#undef DGPU_HIST_LAUNCH_NT
     DGPU_HIP(hipGetLastError());
   } else {
     // caller-supplied histogram: stand-alone normalisation
@@ -1580,6 +1596,7 @@ void dgpu_debug_set_absent_workgroups(uint32_t modulo) { g_absentModulo.store(mo
 void dgpu_debug_set_param_cache(int on) { g_paramCacheEnabled.store(on != 0); }
 void dgpu_debug_set_fused(int mode) { g_fusedMode.store(mode < 0 ? -1 : (mode != 0)); }
 int dgpu_has_fused(void) { return DGPU_WITH_FUSED; }
+void dgpu_set_histogram_load_policy(int mode) { g_histLoadPolicy.store(mode < 0 ? -1 : (mode != 0)); }
 int dgpu_release_graph_state(void) {
   const int n = paramCache().releaseGraphPins();
   return n + streamRegistry().release(nullptr, true, true);
@@ -2052,7 +2069,7 @@ int dgpu_ans_histogram_batch_stride(
   noFuse.arrive = nullptr;
   noFuse.acc = nullptr;
   noFuse.norm = NormalizeArgs{};
-  hipLaunchKernelGGL((k_histogram<kHistSlotsLarge>), grid, dim3(256), 0, (hipStream_t)stream, in, histogram_dev, 0u, noFuse);
+  hipLaunchKernelGGL((k_histogram<kHistSlotsLarge, true>), grid, dim3(256), 0, (hipStream_t)stream, in, histogram_dev, 0u, noFuse);
   DGPU_HIP(hipGetLastError());
   return DGPU_OK;
 }

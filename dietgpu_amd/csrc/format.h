@@ -24,13 +24,15 @@
 // one buffer set):
 //   * decoded float words are written once and not read again by the codec: non-temporal stores
 //   * the encoder's input reads are a one-shot stream: non-temporal loads
-//   * the histogram pass of 16-BIT FLOAT inputs reads with ORDINARY loads (DGPU_NT_HIST_LOADS_F16 = 0): they
-//     allocate in the memory-side cache and thereby push out the dirty lines the previous kernels left there (the
-//     decoder's output) while this read-only kernel has write bandwidth to spare -- the histogram takes 64 instead
-//     of 46 us, the decoder that follows 80 instead of 117 (it no longer waits for write-backs to make room for
-//     its own stores), and the encoder's read of the same words hits the cache: 256 x 512 Ki bf16 0.2515 -> 0.228 ms
-//     per step on rotating buffers, fp16 0.256 -> 0.234 (profiles/r03_ab_cache_policy_rotating*.txt).  Raw bytes
-//     and fp32 lose with it (+3 % / +13 %) and keep non-temporal histogram loads.
+//   * the histogram pass reads with non-temporal loads too.  Its policy is the one knob that is also a RUN-TIME
+//     choice (dgpu_set_histogram_load_policy): with ORDINARY (allocating) loads the read-only histogram pass pushes
+//     the dirty lines earlier kernels left in the memory-side cache out while it has write bandwidth to spare, and the
+//     encoder then reads its input from that cache.  In a loop that compresses and at once decompresses on rotating
+//     buffers this is worth 9 % (bf16 0.2515 -> 0.228 ms per step: the decoder no longer waits for write-backs to make
+//     room for its own stores); in every arrangement that resembles use -- compress only, compress after a producer
+//     kernel has written the tensor, one buffer set -- it LOSES 4-20 % (the histogram takes 52-72 us instead of 46-52),
+//     so it is not the default ("cache policy"; profiles/r03_ab_cache_policy_*.txt,
+//     profiles/r03_rotating_phases.txt)
 //   * archive stores stay cacheable: the consumer (decode, a send) follows soon
 #ifndef DGPU_NT_DEC_STORES
 #define DGPU_NT_DEC_STORES 1
@@ -42,7 +44,7 @@
 #define DGPU_NT_HIST_LOADS 1
 #endif
 #ifndef DGPU_NT_HIST_LOADS_F16
-#define DGPU_NT_HIST_LOADS_F16 0
+#define DGPU_NT_HIST_LOADS_F16 1
 #endif
 #ifndef DGPU_NT_ENC_LOADS
 #define DGPU_NT_ENC_LOADS 1
@@ -87,7 +89,7 @@ constexpr uint32_t kFloatVersion = 0x0001u;
 constexpr uint32_t kBlockAlignWords = 8;   // 16 bytes of u16
 
 constexpr uint32_t kFloat16 = 1, kBFloat16 = 2, kFloat32 = 3;
-// cache policy of the histogram pass's input loads, by input type (see the top of this file)
+// default cache policy of the histogram pass's input loads, by input type (see the top of this file)
 __host__ __device__ constexpr bool histLoadsNonTemporal(uint32_t ft) {
   return (ft == kFloat16 || ft == kBFloat16) ? (DGPU_NT_HIST_LOADS_F16 != 0) : (DGPU_NT_HIST_LOADS != 0);
 }

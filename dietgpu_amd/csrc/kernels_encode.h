@@ -983,7 +983,7 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
 // (the histogram the reference fuses into splitFloat,
 // GpuFloatCompress.cuh:144, 352-364).  grid = (xBlocks, B), 256 threads;
 // hist must be zeroed first.
-template <uint32_t FT, uint32_t S>
+template <uint32_t FT, uint32_t S, bool kNt = true>
 __global__ __launch_bounds__(256) void k_float_histogram(BatchView in, uint32_t* __restrict__ hist, uint32_t partial, HistFuse fuse) {
   __shared__ uint32_t bins[kNumSymbols * S];
   const uint32_t tid = threadIdx.x;
@@ -1021,13 +1021,13 @@ __global__ __launch_bounds__(256) void k_float_histogram(BatchView in, uint32_t*
   // four 16-byte loads in flight per lane (the kernel is HBM-latency bound otherwise)
   uint32_t v = blockIdx.x * 256u + tid;
   for (; v + 3u * stride < numVec; v += 4u * stride) {
-    const uint4 x0 = streamLoad<histLoadsNonTemporal(FT)>(&pv[v]), x1 = streamLoad<histLoadsNonTemporal(FT)>(&pv[v + stride]), x2 = streamLoad<histLoadsNonTemporal(FT)>(&pv[v + 2u * stride]), x3 = streamLoad<histLoadsNonTemporal(FT)>(&pv[v + 3u * stride]);
+    const uint4 x0 = streamLoad<kNt>(&pv[v]), x1 = streamLoad<kNt>(&pv[v + stride]), x2 = streamLoad<kNt>(&pv[v + 2u * stride]), x3 = streamLoad<kNt>(&pv[v + 3u * stride]);
     addVec(x0);
     addVec(x1);
     addVec(x2);
     addVec(x3);
   }
-  for (; v < numVec; v += stride) addVec(streamLoad<histLoadsNonTemporal(FT)>(&pv[v]));
+  for (; v < numVec; v += stride) addVec(streamLoad<kNt>(&pv[v]));
 
   // tail (and the whole element when the input is not 16-byte aligned)
   for (uint32_t i = numVec * kWordsPerVec + blockIdx.x * 256u + tid; i < n; i += stride) {

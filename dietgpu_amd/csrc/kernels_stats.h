@@ -453,7 +453,7 @@ __device__ __forceinline__ void histStore(uint32_t* __restrict__ hist, uint32_t 
   }
 }
 
-template <uint32_t S>
+template <uint32_t S, bool kNt = true>
 __global__ __launch_bounds__(256) void k_histogram(BatchView in, uint32_t* __restrict__ hist, uint32_t partial, HistFuse fuse) {
   __shared__ uint32_t bins[kNumSymbols * S];
   const uint32_t tid = threadIdx.x;
@@ -478,14 +478,14 @@ __global__ __launch_bounds__(256) void k_histogram(BatchView in, uint32_t* __res
   const uint32_t stride = gridDim.x * 256u;
   uint32_t i = blockIdx.x * 256u + tid;
   for (; i + 3u * stride < numVec; i += 4u * stride) {
-    const uint4 v0 = streamLoad<histLoadsNonTemporal(0u)>(&pv[i]), v1 = streamLoad<histLoadsNonTemporal(0u)>(&pv[i + stride]), v2 = streamLoad<histLoadsNonTemporal(0u)>(&pv[i + 2u * stride]), v3 = streamLoad<histLoadsNonTemporal(0u)>(&pv[i + 3u * stride]);
+    const uint4 v0 = streamLoad<kNt>(&pv[i]), v1 = streamLoad<kNt>(&pv[i + stride]), v2 = streamLoad<kNt>(&pv[i + 2u * stride]), v3 = streamLoad<kNt>(&pv[i + 3u * stride]);
     histAdd4<S>(myBins, v0.x); histAdd4<S>(myBins, v0.y); histAdd4<S>(myBins, v0.z); histAdd4<S>(myBins, v0.w);
     histAdd4<S>(myBins, v1.x); histAdd4<S>(myBins, v1.y); histAdd4<S>(myBins, v1.z); histAdd4<S>(myBins, v1.w);
     histAdd4<S>(myBins, v2.x); histAdd4<S>(myBins, v2.y); histAdd4<S>(myBins, v2.z); histAdd4<S>(myBins, v2.w);
     histAdd4<S>(myBins, v3.x); histAdd4<S>(myBins, v3.y); histAdd4<S>(myBins, v3.z); histAdd4<S>(myBins, v3.w);
   }
   for (; i < numVec; i += stride) {
-    const uint4 v = streamLoad<histLoadsNonTemporal(0u)>(&pv[i]);
+    const uint4 v = streamLoad<kNt>(&pv[i]);
     histAdd4<S>(myBins, v.x);
     histAdd4<S>(myBins, v.y);
     histAdd4<S>(myBins, v.z);

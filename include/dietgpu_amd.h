@@ -324,6 +324,14 @@ void dgpu_debug_set_param_cache(int on);
 void dgpu_debug_set_fused(int mode);
 int dgpu_has_fused(void);
 
+/* Cache policy of the encoder's histogram pass (its first kernel; the second reads the same input again): 0 = the
+ * input is read with non-temporal loads (default), 1 = with ordinary loads, which allocate in the 256 MiB memory-side
+ * cache -- the pass then also pays for evicting whatever dirty lines sit there and the encode kernel reads its input
+ * from the cache.  Worth ~9 % where the codec's own output is what fills the cache (compress followed at once by
+ * decompress on the same device, on buffers that change every call), a loss of 4-20 % otherwise (DESIGN.md
+ * section 5).  -1 restores the default.  Process-wide; archives are identical either way. */
+void dgpu_set_histogram_load_policy(int mode);
+
 /* HIP graphs.  A call made while its stream is being captured (hipStreamBeginCapture) bakes library-owned device
  * addresses into the graph: the resident copy of its pointer / size arrays and the stream's hand-off counters and
  * overflow slab.  The library pins them -- they are neither evicted nor trimmed nor released by

@@ -1501,3 +1501,81 @@ def test_one_gi_bf16_words_and_the_size_guard(dg):
     big = torch.zeros((guard + 4,), dtype=torch.uint8, device=DEV)
     with pytest.raises(Exception, match="INT32_MAX|1717538816"):
         dg.compress_data(False, [big])
+
+
+def test_histogram_load_policy_does_not_change_archives(dg):
+    # dgpu_set_histogram_load_policy only changes the cache policy of the histogram pass's loads
+    L = dg.lib()
+    w = refgen.generate_floats(O.BFLOAT16, 70 * 4096 + 123)
+    x = refgen.generate_symbols(50 * 4096 + 7, 30.0)
+    t, tx = words_to_tensor(O.BFLOAT16, w), to_dev_bytes(x)
+    try:
+        for mode in (1, 0, -1):
+            L.dgpu_set_histogram_load_policy(mode)
+            comp, sizes, _ = dg.compress_data(True, [t])
+            n = int(sizes[0].item())
+            want = O.float_compress(O.BFLOAT16, w, 10)
+            assert n == want.size and (comp[0, :n].cpu().numpy() == want).all(), mode
+            comp, sizes, _ = dg.compress_data(False, [tx])
+            n = int(sizes[0].item())
+            want = O.ans_encode(x, 10)
+            assert n == want.size and (comp[0, :n].cpu().numpy() == want).all(), mode
+    finally:
+        L.dgpu_set_histogram_load_policy(-1)
+
+
+@pytest.mark.parametrize("ft", [O.FLOAT16, O.BFLOAT16, O.FLOAT32])
+def test_capped_stride_compress_and_bounded_stride_decompress(dg, ft):
+    # dgpu_float_compress_stride_capped: rows of one matrix compressed straight into the rows of a send matrix at a
+    # fixed width.  With room for everything the rows are the oracle's archives; with less, every byte below the
+    # capacity is still the oracle's, nothing at or beyond it is written, outSize reports the full size, and the
+    # bounded decoder rejects exactly the rows that did not fit (incompressible rows take the encoder's spill path).
+    L = dg.lib()
+    rng = np.random.default_rng(40 + ft)
+    n, B = 9 * 4096 + 40, 6
+    wdt = np.uint32 if ft == O.FLOAT32 else np.uint16
+    rows = [refgen.generate_floats(ft, n) for _ in range(B)]
+    bits = 32 if ft == O.FLOAT32 else 16
+    rows[2] = rng.integers(0, 1 << bits, n, dtype=np.uint64).astype(wdt)  # incompressible
+    rows[5] = rng.integers(0, 1 << bits, n, dtype=np.uint64).astype(wdt)
+    mat = torch.stack([words_to_tensor(ft, r) for r in rows])
+    want = [O.float_compress(ft, r, 10) for r in rows]
+    cap_full = int(L.dgpu_float_max_compressed_size(ft, n))
+    normal = max(a.size for i, a in enumerate(want) if i not in (2, 5))
+    width = (normal + 64 + 15) // 16 * 16            # fits the compressible rows, not the noise
+    assert all(want[i].size > width for i in (2, 5))
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    eb = mat.element_size()
+    for cap, stride in ((cap_full, cap_full), (width, width), (width, width + 4096)):
+        out = torch.full((B, stride), 0xAB, dtype=torch.uint8, device=DEV)
+        sizes = torch.zeros((B,), dtype=torch.int32, device=DEV)
+        rc = L.dgpu_float_compress_stride_capped(None, 0, None, ft, 10, 0, B, C.c_void_p(mat.data_ptr()), n, n * eb,
+                                                 C.c_void_p(out.data_ptr()), stride, cap, C.c_void_p(sizes.data_ptr()), stream)
+        assert rc == 0, L.dgpu_last_error()
+        torch.cuda.synchronize()
+        got, hs = out.cpu().numpy(), sizes.cpu().numpy()
+        for i in range(B):
+            assert hs[i] == want[i].size
+            k = min(want[i].size, cap)
+            assert (got[i, :k] == want[i][:k]).all(), (cap, i, int(np.flatnonzero(got[i, :k] != want[i][:k])[0]))
+            assert (got[i, max(k, min(cap, (want[i].size + 15) // 16 * 16)):] == 0xAB).all(), (cap, i)  # nothing beyond
+        dec = torch.zeros_like(mat)
+        status = torch.full((B,), 7, dtype=torch.uint8, device=DEV)
+        err = C.c_int32(-1)
+        rc = L.dgpu_float_decompress_stride_bounded(None, 0, None, ft, 10, 0, B, C.c_void_p(out.data_ptr()), stride, cap,
+                                                    C.c_void_p(dec.data_ptr()), n * eb, n, C.c_void_p(status.data_ptr()), None,
+                                                    stream, C.byref(err))
+        assert rc == 0, L.dgpu_last_error()
+        torch.cuda.synchronize()
+        st = status.cpu().tolist()
+        fits = [1 if want[i].size <= cap else 0 for i in range(B)]
+        assert st == fits, (cap, st, fits)
+        view = torch.int32 if ft == O.FLOAT32 else torch.int16
+        for i in range(B):
+            if fits[i]:
+                assert torch.equal(dec[i].view(view), mat[i].view(view))
+    # a capacity that cannot even hold the tables and the non-compressed plane is an argument error
+    out = torch.empty((B, 4096), dtype=torch.uint8, device=DEV)
+    rc = L.dgpu_float_compress_stride_capped(None, 0, None, ft, 10, 0, B, C.c_void_p(mat.data_ptr()), n, n * eb,
+                                             C.c_void_p(out.data_ptr()), 4096, 4096, None, stream)
+    assert rc == 1  # DGPU_ERR_INVALID_ARGUMENT

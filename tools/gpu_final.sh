@@ -6,6 +6,10 @@ T=${1:-r03}
 mkdir -p gpurun_out
 ( timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 ) > gpurun_out/${T}_pytest.txt
 tail -3 gpurun_out/${T}_pytest.txt
+# the two experimental kernels on their own builds (tools/build_variant.py fused -DDGPU_WITH_FUSED=1 / mt -DDGPU_WITH_DEC_MT=1)
+[ -f dietgpu_amd/lib/v_fused.so ] && ( DGPU_LIB=$PWD/dietgpu_amd/lib/v_fused.so timeout 600 python -m pytest tests/test_gpu_fused.py -m gpu -x -q 2>&1 | tail -2 ) > gpurun_out/${T}_pytest_fused_build.txt
+[ -f dietgpu_amd/lib/v_mt.so ] && ( DGPU_LIB=$PWD/dietgpu_amd/lib/v_mt.so DGPU_DEC_MT=1 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "decode_mt or ans_ or config2 or fuzz or staging or rejects" 2>&1 | tail -2 ) > gpurun_out/${T}_pytest_decode_mt_build.txt
+cat gpurun_out/${T}_pytest_fused_build.txt gpurun_out/${T}_pytest_decode_mt_build.txt
 python bench.py > gpurun_out/${T}_bench_bf16.json 2>/dev/null
 python bench.py --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/${T}_bench_bf16_driver_protocol.json 2>/dev/null
 for w in u8 fp16 fp32; do python bench.py --no-cpu-baseline --workload $w > gpurun_out/${T}_bench_$w.json 2>/dev/null; done
@@ -14,6 +18,7 @@ for s in "8192 16384" "16384 8192" "32768 4096" "1 134217728" "16 8388608" "2048
 python bench.py --collective --no-cpu-baseline --chunks 1 > gpurun_out/${T}_bench_collective_world1.json 2>/dev/null
 python bench.py --collective --no-cpu-baseline --chunks 1 --workload fp16 > gpurun_out/${T}_bench_collective_world1_fp16.json 2>/dev/null
 python bench.py --reference-protocol > gpurun_out/${T}_reference_protocol.json 2>/dev/null
+python tools/rotating_phases.py > gpurun_out/${T}_rotating_phases.txt 2>/dev/null
 python tools/graph_rate.py > gpurun_out/${T}_graph_rate.txt 2>/dev/null
 python tools/api_rate.py > gpurun_out/${T}_api_rate.txt 2>/dev/null
 for w in bf16 u8 fp16 fp32; do tools/gpu_profile.sh $T $w > /dev/null 2>&1; done
@@ -30,6 +35,7 @@ for f in sorted(glob.glob("gpurun_out/${T}_bench_*.json")):
         if "ms_per_step" in d:
             print(f.split("/")[-1], d["ms_per_step"], "no_preroll", d.get("ms_per_step_no_preroll"), "rotating", d.get("ms_per_step_rotating"), d["value"], d.get("step_frac_of_hbm_peak"),
                   d.get("step_frac_of_hbm_peak_rotating"), d.get("round_trip_bit_exact"), {k[6:]: v["avg_us"] for k, v in d.get("kernels", {}).items()}, d.get("kernels_rotating_avg_us"),
+                  "one-direction", d.get("ms_compress_only_rotating"), d.get("ms_decompress_only_rotating"), "cached-hist", d.get("ms_per_step_rotating_cached_histogram_loads"),
                   "traffic", (d.get("roofline") or {}).get("traffic"))
         else:
             print(f.split("/")[-1], d.get("ms_compressed"), d.get("ms_plain"), d.get("config"))
