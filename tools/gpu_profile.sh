@@ -5,10 +5,10 @@ TAG=${1:-run}; WL=${2:-bf16}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/gpurun_out /tmp/prof_$TAG
-CMD="python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --workload $WL"
+CMD="python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --workload $WL $PROFILE_ARGS"
 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG/stats -o bench -- $CMD > /tmp/prof_$TAG/bench.json 2> /tmp/prof_$TAG/err.log
 {
-  echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline --workload $WL"
+  echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline --workload $WL $PROFILE_ARGS"
   python $R/tools/rocpd_summary.py stats /tmp/prof_$TAG/stats/bench_results.db | grep -v "at::native\|rocclr\|elementwise"
   echo
   echo "# bench line printed by the same (profiled) command"
