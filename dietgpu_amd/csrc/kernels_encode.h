@@ -382,13 +382,27 @@ __device__ __forceinline__ uint2 ldsTableEntry8(uint32_t addr) {
   return make_uint2(v.x, v.y);
 }
 
-// DGPU_ENC_EXEC_WRITE: the emitting lanes of a full-block row store under the row's ballot as execution mask (two
-// scalar moves) instead of every lane storing, the non-emitting ones to a scratch slot (one v_cndmask per row).
+// DGPU_ENC_EXEC_WRITE: the emitting lanes of a full-block row store under the row's ballot as execution mask (1: two
+// s_mov instead of the v_cndmask that parks the idle lanes' store on a scratch slot; 2: the renormalisation shift of the
+// emitting lanes happens in the same exec window as well -- two v_cndmask fewer per row).  -1 (default) = by element
+// type, as measured on MI355X with tools/gpu_r3m.sh (profiles/r03_ab_encoder_exec_write.txt): 2 for raw bytes (encode
+// 163.2 -> 152.7 us on 256 x 1 MiB) and bfloat16 (87.2 / 82.8 -> 81.2 us), 1 for float16 (83.2 -> 82.2 us; 86.5 us
+// with 2) and float32 (no difference between the three).  Archives are byte-identical either way.
 #ifndef DGPU_ENC_EXEC_WRITE
-#define DGPU_ENC_EXEC_WRITE 0
+#define DGPU_ENC_EXEC_WRITE -1
 #endif
+template <uint32_t FT>
+constexpr int encExecWrite() {
+  return DGPU_ENC_EXEC_WRITE >= 0 ? DGPU_ENC_EXEC_WRITE : ((FT == 0u || FT == kBFloat16) ? 2 : 1);
+}
 __device__ __forceinline__ void stageWriteUnder(uint64_t vote, uint32_t addr, uint32_t state) {
   asm volatile("s_mov_b64 exec, %2\n\tds_write_b16 %0, %1\n\ts_mov_b64 exec, -1" : : "v"(addr), "v"(state), "s"(vote) : "memory");
+}
+// ... and the renormalisation shift of the emitting lanes in the same exec window (DGPU_ENC_EXEC_WRITE=2: two
+// v_cndmask fewer per row for two s_mov)
+__device__ __forceinline__ void stageWriteShiftUnder(uint64_t vote, uint32_t addr, uint32_t& state) {
+  asm volatile("s_mov_b64 exec, %[v]\n\tds_write_b16 %[a], %[s]\n\tv_lshrrev_b32 %[s], 16, %[s]\n\ts_mov_b64 exec, -1"
+               : [s] "+v"(state) : [a] "v"(addr), [v] "s"(vote) : "memory");
 }
 
 template <int P, uint32_t FT, bool kFull, bool kSpill, bool kEntry8 = false>
@@ -406,6 +420,7 @@ __device__ __forceinline__ uint32_t encodeRows(
     uint16_t* __restrict__ spill,         // this half's spill slot (kSpill only)
     uint32_t& spilledOut,                 // words flushed to it (multiple of 8)
     uint32_t& stateOut) {
+  constexpr int kExecWrite = encExecWrite<FT>();
   const uint32_t laneMaskLt = (1u << hl) - 1u;
   uint32_t state = kStartState;
   uint32_t outOff = 0;
@@ -479,7 +494,30 @@ __device__ __forceinline__ uint32_t encodeRows(
   // Full-block step: straight-line code, no exec-mask change and no branch.
   // (A hand-scheduled variant of this step with an SDWA select -- two instructions
   // shorter -- measured 5 % slower: see DESIGN.md section 4.1.)
+  // DGPU_ENC_ABLATE (timing experiments only, archives are WRONG): 1 = constant table entry (no table read), 2 = no
+  // stage write, 3 = constant symbol (every lane reads entry 0: no bank conflicts), 4 = no division (shift instead of
+  // mul_hi), 5 = constant emit address (no position arithmetic), 6 = never emit (no ballot-dependent work at all)
+#ifndef DGPU_ENC_ABLATE
+#define DGPU_ENC_ABLATE 0
+#endif
   auto stepFullC = [&](const uint4 e) {
+#if DGPU_ENC_ABLATE == 6
+    {
+      const uint32_t div = __umulhi(state, e.y) >> (e.w >> 24);
+      state = (__umul24(div, e.w) + state + e.z) & 0x7fffffffu;
+      return;
+    }
+#endif
+#if DGPU_ENC_ABLATE == 5
+    {
+      const bool write5 = state >= e.x;
+      *(LdsU16e*)(uintptr_t)dummyAddr = (uint16_t)state;
+      state = write5 ? (state >> kEncodedBits) : state;
+      const uint32_t div = __umulhi(state, e.y) >> (e.w >> 24);
+      state = __umul24(div, e.w) + state + e.z;
+      return;
+    }
+#endif
     const bool write = state >= e.x;
     const uint64_t vote = __ballot(write);
     if (kScalarPos) {
@@ -501,16 +539,20 @@ __device__ __forceinline__ uint32_t encodeRows(
     }
     const uint32_t vh = upper ? (uint32_t)(vote >> 32) : (uint32_t)vote;
     const uint32_t idx = outOff + __popc(vh & laneMaskLt);
-    if (DGPU_ENC_EXEC_WRITE) {
+    if (kExecWrite == 2) {
+      stageWriteShiftUnder(vote, stageBase + 2u * idx, state);
+    } else if (kExecWrite) {
       stageWriteUnder(vote, stageBase + 2u * idx, state);
-    } else {
+    } else if (DGPU_ENC_ABLATE != 2) {
       const uint32_t addr = write ? stageBase + 2u * idx : dummyAddr;
       *(LdsU16e*)(uintptr_t)addr = (uint16_t)state;
     }
-    state = write ? (state >> kEncodedBits) : state;
-    const uint32_t div = __umulhi(state, e.y) >> (e.w >> 24);
+    if (kExecWrite != 2) state = write ? (state >> kEncodedBits) : state;
+    const uint32_t div = DGPU_ENC_ABLATE == 4 ? (state >> 9) : (__umulhi(state, e.y) >> (e.w >> 24));
     state = __umul24(div, e.w) + state + e.z;
+    if (DGPU_ENC_ABLATE == 4) state &= 0x7fffffffu;
     outOff += __popc(vh);
+    if (DGPU_ENC_ABLATE) outOff &= 1023u;  // (wrong tables may emit more than a stage holds)
   };
   // the same step on a packed 8-byte entry
   auto stepFullC8 = [&](const uint2 p) {
@@ -520,7 +562,7 @@ __device__ __forceinline__ uint32_t encodeRows(
     const uint64_t vote = __ballot(write);
     const uint32_t vh = upper ? (uint32_t)(vote >> 32) : (uint32_t)vote;
     const uint32_t idx = outOff + __popc(vh & laneMaskLt);
-    if (DGPU_ENC_EXEC_WRITE) {
+    if (kExecWrite) {
       stageWriteUnder(vote, stageBase + 2u * idx, state);
     } else {
       const uint32_t addr = write ? stageBase + 2u * idx : dummyAddr;
@@ -556,10 +598,20 @@ __device__ __forceinline__ uint32_t encodeRows(
 #endif
       constexpr int kSymAhead = DGPU_ENC_SYM_AHEAD;
       static_assert(kSymAhead > kAhead && kSymAhead <= (int)kChunkRows, "a symbol slot is reused only after its table load was issued");
+      // DGPU_ENC_LATE_ADDR: the window holds the raw symbol values and the table address is formed where the table
+      // entry is fetched (two rows after the symbol was requested), not where the symbol is requested: with the
+      // address pinned at the request (0) every row waits for the LDS round trip of the byte it has just asked for.
+#ifndef DGPU_ENC_LATE_ADDR
+#define DGPU_ENC_LATE_ADDR 1
+#endif
       auto symAddr = [&](int r) -> uint32_t {
+        if (DGPU_ENC_LATE_ADDR) return (uint32_t)ring[r * 32 + hl];
         uint32_t t = tableLds + ((uint32_t)ring[r * 32 + hl] << (kEntry8 ? 3 : 4));
         asm volatile("" : "+v"(t));  // keep the scaled address; do not re-derive it (with a mask) at the use
         return t;
+      };
+      auto entryAddr = [&](uint32_t v) -> uint32_t {
+        return DGPU_ENC_LATE_ADDR ? tableLds + (v << (kEntry8 ? 3 : 4)) : v;
       };
       uint32_t toff[kSymAhead];
 #pragma unroll
@@ -567,24 +619,33 @@ __device__ __forceinline__ uint32_t encodeRows(
       if constexpr (kEntry8) {
         uint2 e[kAhead];
 #pragma unroll
-        for (int r = 0; r < kAhead; ++r) e[r] = ldsTableEntry8(toff[r]);
+        for (int r = 0; r < kAhead; ++r) e[r] = ldsTableEntry8(entryAddr(toff[r]));
 #pragma unroll
         for (int r = 0; r < (int)kChunkRows; ++r) {
           if (r % kFlushRows == 0) makeRoom();
           const uint2 cur_e = e[r % kAhead];
-          if (r + kAhead < (int)kChunkRows) e[r % kAhead] = ldsTableEntry8(toff[(r + kAhead) % kSymAhead]);
+          if (r + kAhead < (int)kChunkRows) e[r % kAhead] = ldsTableEntry8(entryAddr(toff[(r + kAhead) % kSymAhead]));
           if (r + kSymAhead < (int)kChunkRows) toff[r % kSymAhead] = symAddr(r + kSymAhead);
           stepFullC8(cur_e);
         }
       } else {
       uint4 e[kAhead];
+      auto fetchEntry = [&](uint32_t v) -> uint4 {
+#if DGPU_ENC_ABLATE == 1
+        return make_uint4(0x00800000u + (v & 0xff0u), 0x80000001u, 3u, 1020u | (1u << 24));  // no LDS read
+#elif DGPU_ENC_ABLATE == 3
+        return ldsTableEntry(tableLds + (v & 0u));  // every lane the same entry
+#else
+        return ldsTableEntry(entryAddr(v));
+#endif
+      };
 #pragma unroll
-      for (int r = 0; r < kAhead; ++r) e[r] = ldsTableEntry(toff[r]);
+      for (int r = 0; r < kAhead; ++r) e[r] = fetchEntry(toff[r]);
 #pragma unroll
       for (int r = 0; r < (int)kChunkRows; ++r) {
         if (r % kFlushRows == 0) makeRoom();
         const uint4 cur_e = e[r % kAhead];
-        if (r + kAhead < (int)kChunkRows) e[r % kAhead] = ldsTableEntry(toff[(r + kAhead) % kSymAhead]);
+        if (r + kAhead < (int)kChunkRows) e[r % kAhead] = fetchEntry(toff[(r + kAhead) % kSymAhead]);
         if (r + kSymAhead < (int)kChunkRows) toff[r % kSymAhead] = symAddr(r + kSymAhead);
         stepFullC(cur_e);
       }
