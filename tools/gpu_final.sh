@@ -22,6 +22,8 @@ python tools/rotating_phases.py > gpurun_out/${T}_rotating_phases.txt 2>/dev/nul
 python tools/graph_rate.py > gpurun_out/${T}_graph_rate.txt 2>/dev/null
 python tools/api_rate.py > gpurun_out/${T}_api_rate.txt 2>/dev/null
 for w in bf16 u8 fp16 fp32; do tools/gpu_profile.sh $T $w > /dev/null 2>&1; done
+# ... and of the one-buffer-set loop alone (what `roofline` in the bench line measures)
+for w in bf16 u8; do PROFILE_ARGS="--rotate 1" tools/gpu_profile.sh ${T}one $w > /dev/null 2>&1; done
 tools/gpu_pmc.sh $T bf16 > /dev/null 2>&1; tools/gpu_pmc.sh $T u8 > /dev/null 2>&1; tools/gpu_pmc.sh $T fp16 > /dev/null 2>&1
 python tools/make_traffic_json.py $T bf16=gpurun_out/pmc_${T}_bf16.txt u8=gpurun_out/pmc_${T}_u8.txt fp16=gpurun_out/pmc_${T}_fp16.txt > gpurun_out/${T}_traffic_summary.txt 2>&1
 cp profiles/${T}_hbm_traffic.json gpurun_out/${T}_hbm_traffic.json
