@@ -20,14 +20,7 @@
 
 #include "format.h"
 #include "kernels_decode.h"
-#ifndef DGPU_WITH_DEC_MT
-#define DGPU_WITH_DEC_MT 0
-#endif
-#if DGPU_WITH_DEC_MT
-#include "kernels_decode_mt.h"
-#endif
 #include "kernels_encode.h"
-#include "kernels_encode_fused.h"
 #include "kernels_pairs.h"
 #include "kernels_stats.h"
 
@@ -147,10 +140,8 @@ struct StreamState {
   uint8_t* slab = nullptr;
   size_t slabCap = 0;
   std::vector<void*> retired;
-  // 65536 arrival counters + kAccElements x 256 histogram counters (zero at rest), then the fused
-  // encoder's 65536 ready flags (epoch-valued) and its ticket / exit counters (zero at rest)
+  // 65536 arrival counters + kAccElements x 256 histogram counters (zero at rest)
   uint32_t* counters = nullptr;
-  uint32_t fusedEpoch = 0;  // value the ready flags of the last fused call were raised to
   // a call was CAPTURED into a HIP graph with pointers into this state (slab, counters): the graph replays without
   // passing through the library, so the state is never trimmed or released implicitly (dgpu_release_graph_state)
   bool graphPinned = false;
@@ -656,15 +647,10 @@ BatchView viewPointers(const uint64_t* ptrs_dev, const uint32_t* sizes_dev, uint
 // tensor up to 256 of them.
 // Raw bytes carry twice the symbols (LDS atomics, address arithmetic) per byte of traffic: three workgroups per CU
 // (256 x 1 MiB Zipf bytes: 53.9 -> 51.3 us; the exponent histogram loses 2 us with three).
-#ifndef DGPU_HIST_TARGET_WGS
-#define DGPU_HIST_TARGET_WGS 512
-#endif
-#ifndef DGPU_HIST_TARGET_WGS_RAW
-#define DGPU_HIST_TARGET_WGS_RAW 768
-#endif
+constexpr uint32_t kHistTargetWgs = 512, kHistTargetWgsRaw = 768, kHistAccWgs = 512, kHistAccMaxBatch = 2;
 uint32_t histPartsFor(uint32_t B, uint32_t maxBytes, bool raw) {
   const uint32_t bySize = divUp(std::max(maxBytes, 1u), 32u * 1024u);
-  const uint32_t byBatch = divUp((uint32_t)(raw ? DGPU_HIST_TARGET_WGS_RAW : DGPU_HIST_TARGET_WGS), std::max(B, 1u));
+  const uint32_t byBatch = divUp(raw ? kHistTargetWgsRaw : kHistTargetWgs, std::max(B, 1u));
   return std::max(1u, std::min(std::min(bySize, byBatch), 256u));
 }
 // One or two large elements: the counts of an element's workgroups meet in 256 library-owned
@@ -674,10 +660,7 @@ uint32_t histPartsFor(uint32_t B, uint32_t maxBytes, bool raw) {
 bool histAccumulates(uint32_t B, uint32_t maxBytes, bool raw);
 uint32_t histPartsAccFor(uint32_t B, uint32_t maxBytes) {
   const uint32_t bySize = divUp(std::max(maxBytes, 1u), 64u * 1024u);
-#ifndef DGPU_HIST_ACC_WGS
-#define DGPU_HIST_ACC_WGS 512
-#endif
-  const uint32_t byBatch = divUp((uint32_t)DGPU_HIST_ACC_WGS, std::max(B, 1u));
+  const uint32_t byBatch = divUp(kHistAccWgs, std::max(B, 1u));
   return std::max(1u, std::min(bySize, byBatch));
 }
 
@@ -716,21 +699,6 @@ struct HostParams {
   std::vector<uint32_t> sizes;
   std::vector<uint32_t> inBytes;  // decode, *_bounded entry points: bytes available per compressed input
 };
-
-// uniform size (0 if the sizes differ) and 16-byte alignment of every input pointer of a pointer batch
-void batchShape(const HostParams& hp, uint32_t* uniformSize, bool* aligned16) {
-  uint32_t u = hp.sizes.empty() ? 0u : hp.sizes[0];
-  for (uint32_t sz : hp.sizes) {
-    if (sz != u) {
-      u = 0;
-      break;
-    }
-  }
-  bool al = true;
-  for (uint64_t p : hp.inPtrs) al = al && (p % 16 == 0);
-  *uniformSize = u;
-  *aligned16 = al;
-}
 
 bool streamIsCapturing(hipStream_t stream) {
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
@@ -784,11 +752,8 @@ bool progression(const std::vector<uint64_t>& p, uint64_t* stride) {
   }
   return !p.empty();
 }
-#ifndef DGPU_STRIDE_DETECT
-#define DGPU_STRIDE_DETECT 1
-#endif
 bool asStrideViews(const HostParams& hp, bool sizesOnOut, BatchView* in, BatchView* out) {
-  if (!DGPU_STRIDE_DETECT || !hp.inBytes.empty() || hp.inPtrs.size() != hp.outPtrs.size()) return false;
+  if (!hp.inBytes.empty() || hp.inPtrs.size() != hp.outPtrs.size()) return false;
   uint64_t inStride = 0, outStride = 0;
   if (!progression(hp.inPtrs, &inStride) || !progression(hp.outPtrs, &outStride)) return false;
   uint32_t u = hp.sizes.empty() ? 0u : hp.sizes[0];
@@ -821,13 +786,8 @@ uint32_t numComputeUnits() {
 
 // The encoder runs as persistent workgroups: as many as fit on the chip at once
 // (or fewer, if there are fewer tiles).  Float inputs use the small-stage /
-// spilling variant (6 workgroups per CU), raw bytes the worst-case stage.  (DGPU_RAW_SPILLS=1 gives raw bytes a
-// 1664-word stage, 4 workgroups per CU instead of 3: 256 x 1 MiB Zipf bytes encode 169.5 -> 164.9 us, but
-// the call then needs ~76 MiB of temp memory for spill slots instead of ~2 MiB; not worth 3 %.)
-#ifndef DGPU_RAW_SPILLS
-#define DGPU_RAW_SPILLS 0
-#endif
-constexpr bool encodeSpills(uint32_t ft) { return ft != 0 || DGPU_RAW_SPILLS; }
+// spilling variant (6 workgroups per CU), raw bytes the worst-case stage (3 per CU; kernels_encode.h).
+constexpr bool encodeSpills(uint32_t ft) { return ft != 0; }
 
 template <int P, uint32_t FT, uint32_t TB>
 uint32_t encodeGridPFT(uint32_t tickets) {
@@ -839,17 +799,9 @@ uint32_t encodeGridPFT(uint32_t tickets) {
     }
     return (uint32_t)n;
   }();
-  static const uint32_t knob = [] {
-    const char* e = getenv("DGPU_ENC_WG_PER_CU");  // experiment knob
-    return e ? (uint32_t)atoi(e) : 0u;
-  }();
-  const uint32_t use = knob ? std::min(knob, perCu) : perCu;
-  return std::max(1u, std::min(tickets, use * numComputeUnits()));
+  return std::max(1u, std::min(tickets, perCu * numComputeUnits()));
 }
 // Batches of single-block elements: two ELEMENTS per wavefront (kernels_pairs.h) instead of one with an idle half.
-#ifndef DGPU_PAIRS
-#define DGPU_PAIRS 1
-#endif
 template <int P, uint32_t FT>
 uint32_t encodePairGridPF(uint32_t elements) {
   static const uint32_t perCu = [] {
@@ -864,9 +816,8 @@ uint32_t encodePairGridPF(uint32_t elements) {
 }
 template <int P, uint32_t FT>
 uint32_t encodeGridPF(uint32_t tickets, uint32_t tileBlocks) {
-  if (DGPU_PAIRS && tileBlocks == kBlocksPerSingleTile) return encodePairGridPF<P, FT>(tickets);  // (one ticket per element)
-  return tileBlocks == kBlocksPerSingleTile  ? encodeGridPFT<P, FT, kBlocksPerSingleTile>(tickets)
-      : tileBlocks == kBlocksPerTinyTile  ? encodeGridPFT<P, FT, kBlocksPerTinyTile>(tickets)
+  if (tileBlocks == kBlocksPerSingleTile) return encodePairGridPF<P, FT>(tickets);  // (one ticket per element)
+  return tileBlocks == kBlocksPerTinyTile ? encodeGridPFT<P, FT, kBlocksPerTinyTile>(tickets)
       : tileBlocks == kBlocksPerSmallTile ? encodeGridPFT<P, FT, kBlocksPerSmallTile>(tickets)
                                           : encodeGridPFT<P, FT, kBlocksPerTile>(tickets);
 }
@@ -874,11 +825,8 @@ uint32_t encodeGridPF(uint32_t tickets, uint32_t tileBlocks) {
 template <int P, uint32_t FT>
 int launchEncodePF(const EncodeArgs& a, uint32_t tileBlocks, uint32_t grid, hipStream_t stream) {
   constexpr bool kSpill = encodeSpills(FT);
-  if (DGPU_PAIRS && tileBlocks == kBlocksPerSingleTile) {
+  if (tileBlocks == kBlocksPerSingleTile) {
     DGPU_LAUNCH("k_ans_encode_pair", stream, (k_ans_encode_pair<P, FT, kSpill>), dim3(grid), dim3(64), encPairLdsBytes(P, kSpill, FT), stream, a);
-  } else if (tileBlocks == kBlocksPerSingleTile) {
-    DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT, kSpill, kBlocksPerSingleTile>), dim3(grid), dim3(encThreads(kBlocksPerSingleTile)),
-                encLdsBytes(P, kSpill, FT, kBlocksPerSingleTile), stream, a);
   } else if (tileBlocks == kBlocksPerTinyTile) {
     DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT, kSpill, kBlocksPerTinyTile>), dim3(grid), dim3(kBlocksPerTinyTile * 32),
                 encLdsBytes(P, kSpill, FT, kBlocksPerTinyTile), stream, a);
@@ -942,10 +890,7 @@ uint32_t tilesFor(uint32_t maxSize) { return divUp(divUp(maxSize, kBlockSize), e
 uint32_t absentWorkgroupModulo();  // test hook, defined with the C ABI below
 
 bool histAccumulates(uint32_t B, uint32_t maxBytes, bool raw) {
-#ifndef DGPU_HIST_ACC_MAX_B
-#define DGPU_HIST_ACC_MAX_B 2
-#endif
-  return B <= (uint32_t)DGPU_HIST_ACC_MAX_B && histPartsAccFor(B, maxBytes) > histPartsFor(B, maxBytes, raw);
+  return B <= kHistAccMaxBatch && histPartsAccFor(B, maxBytes) > histPartsFor(B, maxBytes, raw);
 }
 
 // Library-owned arrival counters for the histogram -> normalisation hand-off
@@ -954,8 +899,6 @@ bool histAccumulates(uint32_t B, uint32_t maxBytes, bool raw) {
 // ordered while calls on different streams may overlap.
 constexpr size_t kCounterWordsArrive = 65536;
 constexpr size_t kCounterWordsAcc = (size_t)kAccElements * kNumSymbols;
-constexpr size_t kCounterWordsReady = 65536;
-constexpr size_t kCounterWordsTickets = (kFusedMaxClasses + 1) * kFusedTicketStride;
 int arrivalCounters(StreamLease& lease, uint32_t** out, uint32_t** acc) {
   hipError_t e = hipSuccess;
   StreamState* s = lease.state(&e);
@@ -966,7 +909,7 @@ int arrivalCounters(StreamLease& lease, uint32_t** out, uint32_t** acc) {
                                 "the stream is being captured: run the same call once before capturing");
     }
     uint32_t* p = nullptr;
-    const size_t words = kCounterWordsArrive + kCounterWordsAcc + kCounterWordsReady + kCounterWordsTickets;
+    const size_t words = kCounterWordsArrive + kCounterWordsAcc;
     DGPU_HIP(hipMalloc((void**)&p, words * sizeof(uint32_t)));
     // once per (device, stream), ordered on the caller's stream ahead of the kernels that use the
     // counters (a plain hipMemset runs on the null stream, which non-blocking streams do not wait for)
@@ -982,142 +925,14 @@ int arrivalCounters(StreamLease& lease, uint32_t** out, uint32_t** acc) {
   return DGPU_OK;
 }
 
-// ---------------------------------------------------------------------------
-// Fused histogram + encode (kernels_encode_fused.h): taken for uniform batches.
-// The kernel is only compiled into builds made with -DDGPU_WITH_FUSED=1 (tools/build_variant.py fused
-// -DDGPU_WITH_FUSED=1): it is parity-green and halves the HBM reads of the encode call, but measured slower than the
-// two-kernel path on every workload, so the default library does not carry it.
-#ifndef DGPU_WITH_FUSED
-#define DGPU_WITH_FUSED 0
-#endif
-std::atomic<int> g_fusedMode{-1};  // -1: environment DGPU_FUSED (default off), 0 / 1: forced (dgpu_debug_set_fused)
-bool fusedEnabled() {
-  if (!DGPU_WITH_FUSED) return false;
-  const int m = g_fusedMode.load();
-  if (m >= 0) return m != 0;
-  static const bool env = [] {
-    const char* e = getenv("DGPU_FUSED");
-    return e && e[0] == '1';  // opt-in: measured slower than the two-kernel path
-  }();
-  return env;
-}
-
-#if DGPU_WITH_FUSED
-template <int P, uint32_t FT>
-uint32_t fusedGridPF(uint32_t tickets) {
-  static const uint32_t perCu = [] {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (k_ans_encode_fused<P, FT>), 256, fusedLdsBytes(P, FT)) != hipSuccess || n < 1) n = 1;
-    return (uint32_t)n;
-  }();
-  static const uint32_t knob = [] {
-    const char* e = getenv("DGPU_FUSED_WG_PER_CU");  // experiment knob
-    return e ? (uint32_t)atoi(e) : 0u;
-  }();
-  const uint32_t use = knob ? std::min(knob, perCu) : perCu;
-  return std::max(1u, std::min(tickets, use * numComputeUnits()));
-}
-template <int P, uint32_t FT>
-int launchFusedPF(const FusedArgs& a, uint32_t grid, hipStream_t stream) {
-  DGPU_LAUNCH("k_ans_encode_fused", stream, (k_ans_encode_fused<P, FT>), dim3(grid), dim3(256), fusedLdsBytes(P, FT), stream, a);
-  DGPU_HIP(hipGetLastError());
-  return DGPU_OK;
-}
-
-#endif
-// Is the batch one the fused kernel takes?  (uniformSize: every element has that many symbols, 0 = ragged)
-bool fusedEligible(uint32_t B, uint32_t uniformSize, bool inputsAligned16, const uint32_t* hist_dev) {
-  if (!fusedEnabled() || hist_dev || !inputsAligned16 || B == 0 || B > kCounterWordsReady) return false;
-  constexpr uint32_t kTileSymbols = kBlocksPerTile * kBlockSize;
-  if (uniformSize == 0 || uniformSize % kTileSymbols) return false;
-  return uniformSize / kTileSymbols <= kFusedMaxTiles;
-}
-
-#if DGPU_WITH_FUSED
-int encodeFused(
-    TempArena& arena, StreamLease& lease, hipStream_t stream, int P, bool useChecksum, uint32_t B,
-    const BatchView& in, const BatchView& archives, uint32_t floatType, uint32_t size,
-    const uint32_t* checksumTemp, uint32_t* outSize_dev) {
-  const uint32_t T = size / (kBlocksPerTile * kBlockSize);
-  uint32_t *arrive = nullptr, *acc = nullptr;
-  int rc = arrivalCounters(lease, &arrive, &acc);
-  if (rc) return rc;
-  hipError_t e = hipSuccess;
-  StreamState* st = lease.state(&e);
-  if (!st) return fail(DGPU_ERR_HIP, std::string("stream state: ") + hipGetErrorString(e));
-  uint32_t* ready = st->counters + kCounterWordsArrive + kCounterWordsAcc;
-  uint32_t* tickets = ready + kCounterWordsReady;
-  if (++st->fusedEpoch == 0) {  // wrapped: flags of 2^32 calls ago would read as raised
-    DGPU_HIP(hipMemsetAsync(ready, 0, kCounterWordsReady * 4, stream));
-    st->fusedEpoch = 1;
-  }
-
-  DGPU_ALLOC(table, uint4, arena, (size_t)B * kNumSymbols);
-  DGPU_ALLOC(histParts, uint32_t, arena, (size_t)B * T * kNumSymbols);
-  DGPU_ALLOC(tileDesc, uint64_t, arena, (size_t)B * T);
-
-  uint32_t grid = 1;
-  DGPU_ENCODE_DISPATCH(P, floatType, grid = (fusedGridPF<kP, kFT>(B * T)));
-  DGPU_ALLOC(spill, uint16_t, arena, (size_t)grid * kBlocksPerTile * encSpillSlotWords(P));
-
-  FusedArgs f;
-  f.in = in;
-  f.out = archives;
-  f.numInBatch = B;
-  f.tiles = T;
-  f.size = size;
-  f.numClasses = std::min(B, kFusedMaxClasses);
-  f.encTable = table;
-  f.histParts = histParts;
-  f.tileDesc = tileDesc;
-  f.arrive = arrive;
-  f.ready = ready;
-  f.epoch = st->fusedEpoch;
-  f.tickets = tickets;
-  f.spill = spill;
-  f.outSize = outSize_dev;
-  f.useChecksum = (useChecksum && floatType) ? 1 : 0;
-  f.checksum = (useChecksum && floatType) ? checksumTemp : nullptr;
-  f.absentModulo = absentWorkgroupModulo();
-  static const uint32_t stagger = [] {
-    const char* e = getenv("DGPU_FUSED_STAGGER");  // experiment knob
-    return e ? (uint32_t)strtoul(e, nullptr, 0) : 0u;
-  }();
-  f.staggerSleeps = stagger;
-  NormalizeArgs& n = f.norm;
-  n.sizes = in;
-  n.hist = histParts;
-  n.histAcc = nullptr;
-  n.histParts = T;
-  n.probBits = P;
-  n.encTable = table;
-  n.refTable = nullptr;
-  n.out = archives;
-  n.writeHeader = 1;
-  n.floatType = floatType;
-  n.useChecksum = (useChecksum && !floatType) ? 1 : 0;
-  n.checksum = (useChecksum && !floatType) ? checksumTemp : nullptr;
-  n.outSize = outSize_dev;
-  n.floatUseChecksum = (useChecksum && floatType) ? 1 : 0;
-  n.tileDesc = nullptr;
-  n.maxTiles = T;
-  n.ticket = nullptr;
-  n.claims = nullptr;
-  n.numInBatch = B;
-  n.inKernelConsumer = 1;
-  DGPU_ENCODE_DISPATCH(P, floatType, rc = (launchFusedPF<kP, kFT>(f, grid, stream)));
-  return rc;
-}
-
-#endif
-
 // Cache policy of the histogram pass's input loads (format.h): non-temporal by default; ordinary (allocating) loads
 // on request (dgpu_set_histogram_load_policy) for pipelines in which the codec's own dirty lines are what fills the
 // memory-side cache when the pass starts.
 std::atomic<int> g_histLoadPolicy{-1};  // -1: the compile-time default per input type, 0: non-temporal, 1: ordinary
 bool histogramLoadsNonTemporal(uint32_t ft) {
   const int m = g_histLoadPolicy.load();
-  return m < 0 ? histLoadsNonTemporal(ft) : m == 0;
+  (void)ft;
+  return m < 0 ? kNtHistLoads : m == 0;
 }
 
 // Shared tail of every encode entry point: [checksum] -> histogram (+ fused
@@ -1130,7 +945,6 @@ bool histogramLoadsNonTemporal(uint32_t ft) {
 int encodeCommon(
     TempArena& arena, StreamLease& lease, hipStream_t stream, int P, bool useChecksum, uint32_t B,
     const BatchView& in, const BatchView& archives, uint32_t floatType, uint32_t maxSize,
-    uint32_t uniformSize /* != 0: every element has this many symbols */, bool inputsAligned16,
     const uint32_t* hist_dev /*may be null*/, uint32_t* outSize_dev,
     uint32_t outCapacity = 0xffffffffu /* bytes at every archive pointer; block data beyond it is dropped */) {
   const uint32_t wordBytes = floatType ? floatWordBytes(floatType) : 1u;
@@ -1148,17 +962,9 @@ int encodeCommon(
     DGPU_HIP(hipGetLastError());
   }
 
-#if DGPU_WITH_FUSED
-  // (not under stream capture: the epoch the ready flags are compared with would be baked into the graph)
-  if (outCapacity == 0xffffffffu && fusedEligible(B, uniformSize, inputsAligned16, hist_dev) && !lease.capturing()) {
-    return encodeFused(arena, lease, stream, P, useChecksum, B, in, archives, floatType, uniformSize, checksumTemp,
-                       outSize_dev);
-  }
-#endif
 
   DGPU_ALLOC(table, uint4, arena, (size_t)B * kNumSymbols);
   DGPU_ALLOC(tileDesc, uint64_t, arena, (size_t)B * std::max(maxTiles, 1u));
-  DGPU_ALLOC(ticket, uint32_t, arena, 64 * kTicketStride);
   DGPU_ALLOC(claims, uint32_t, arena, (size_t)B * std::max(maxTiles, 1u));
 
   NormalizeArgs n;
@@ -1179,10 +985,8 @@ int encodeCommon(
   n.floatUseChecksum = (useChecksum && floatType) ? 1 : 0;
   n.tileDesc = tileDesc;
   n.maxTiles = maxTiles;
-  n.ticket = ticket;
   n.claims = claims;
   n.numInBatch = B;
-  n.inKernelConsumer = 0;
 
   if (!hist_dev) {
     const bool accumulate = histAccumulates(B, maxSize * wordBytes, floatType == 0);
@@ -1243,7 +1047,7 @@ int encodeCommon(
     uint16_t* spill = nullptr;
     if (encodeSpills(floatType)) {
       // (single-block batches: two slots per workgroup, one per element of its pair)
-      const uint32_t slotsPerWg = (DGPU_PAIRS && tileBlocks == kBlocksPerSingleTile) ? 2u : tileBlocks;
+      const uint32_t slotsPerWg = tileBlocks == kBlocksPerSingleTile ? 2u : tileBlocks;
       DGPU_ALLOC(sp, uint16_t, arena, (size_t)grid * slotsPerWg * encSpillSlotWords(P));
       spill = sp;
     }
@@ -1255,7 +1059,6 @@ int encodeCommon(
     e.numInBatch = B;
     e.numTickets = B * maxTiles;
     e.tileDesc = tileDesc;
-    e.ticket = ticket;
     e.claims = claims;
     e.absentModulo = absentWorkgroupModulo();
     e.spill = spill;
@@ -1297,16 +1100,7 @@ int ansEncodeImpl(
     in = *strideIn;
     out = *strideOut;
   }
-  uint32_t uniformSize = 0;
-  bool aligned16 = false;
-  if (hp) {
-    batchShape(*hp, &uniformSize, &aligned16);
-  } else {
-    uniformSize = strideIn->uniformSize;
-    aligned16 = strideIn->base % 16 == 0 && (B <= 1 || strideIn->stride % 16 == 0);
-  }
-  int rc = encodeCommon(arena, streamLease, stream, P, useChecksum != 0, B, in, out, 0, maxSize, uniformSize, aligned16,
-                        histogram_dev, outSize_dev);
+  int rc = encodeCommon(arena, streamLease, stream, P, useChecksum != 0, B, in, out, 0, maxSize, histogram_dev, outSize_dev);
   if (tempUsed) *tempUsed = arena.requested();
   return rc;
 }
@@ -1337,79 +1131,26 @@ int floatCompressImpl(
   }
 
   // No exponent plane in temp memory: the encoder splits the float words itself.
-  uint32_t uniformSize = 0;
-  bool aligned16 = false;
-  batchShape(hp, &uniformSize, &aligned16);
-  rc = encodeCommon(arena, streamLease, stream, P, useChecksum != 0, B, in, out, ft, maxSize, uniformSize, aligned16, nullptr,
-                    outSize_dev);
+  rc = encodeCommon(arena, streamLease, stream, P, useChecksum != 0, B, in, out, ft, maxSize, nullptr, outSize_dev);
   if (tempUsed) *tempUsed = arena.requested();
   return rc;
 }
 
-// k_ans_decode_mt (kernels_decode_mt.h: several blocks per wavefront, scalar ring maintenance, element slices per
-// workgroup) is only compiled into builds made with -DDGPU_WITH_DEC_MT=1: byte-exact, but SLOWER than k_ans_decode on
-// every geometry tried ("Config 2").  There DGPU_DEC_MT selects the decoder raw-byte elements
-// of more than 8 blocks get: 0 = k_ans_decode's 16-block tiles, 1 = two chains per wavefront on 1 KiB rings, 2 = one
-// chain on 2 KiB rings, 3 = two chains on 2 KiB rings with 4-wavefront workgroups.
-#ifndef DGPU_DEC_MT
-#define DGPU_DEC_MT 1
-#endif
-int decodeMtVariant() {
-  if (!DGPU_WITH_DEC_MT) return 0;
-  static const int v = [] {
-    const char* e = getenv("DGPU_DEC_MT");
-    return e ? atoi(e) : (int)DGPU_DEC_MT;
-  }();
-  return v;
-}
-
 template <int P, uint32_t FT>
 int launchDecodePF(const DecodeArgs& a, uint32_t tileBlocks, dim3 grid, hipStream_t stream) {
-  if (DGPU_PAIRS && tileBlocks == kDecBlocksPerSingleTile) {
+  if (tileBlocks == kDecBlocksPerSingleTile) {
     // every capacity <= 4096 symbols: two elements per wavefront (kernels_pairs.h)
     DGPU_LAUNCH("k_ans_decode_pair", stream, (k_ans_decode_pair<P, FT>), dim3((a.numInBatch + 1u) / 2u), dim3(64), decPairLdsBytes(P, FT),
                 stream, a);
-  } else if (tileBlocks == kDecBlocksPerSingleTile) {
-    DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode<P, FT, kDecBlocksPerSingleTile>), grid, dim3(decThreads(kDecBlocksPerSingleTile)),
-                decLdsBytes(P, FT, kDecBlocksPerSingleTile), stream, a);
   } else if (tileBlocks == kDecBlocksPerTinyTile) {
     DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode<P, FT, kDecBlocksPerTinyTile>), grid, dim3(kDecBlocksPerTinyTile * 32u),
                 decLdsBytes(P, FT, kDecBlocksPerTinyTile), stream, a);
   } else if (tileBlocks == kDecBlocksPerSmallTile) {
     DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode<P, FT, kDecBlocksPerSmallTile>), grid, dim3(kDecBlocksPerSmallTile * 32u),
                 decLdsBytes(P, FT, kDecBlocksPerSmallTile), stream, a);
-#if DGPU_WITH_DEC_MT
-  } else if (tileBlocks == kDecBlocksPerTile && FT == 0 && decodeMtVariant() != 0) {
-    // raw bytes, elements of more than 8 blocks: several blocks per wavefront / scalar ring maintenance
-    // (kernels_decode_mt.h).  A workgroup takes a slice of an element: as many rounds as leaves every CU its
-    // share of workgroups.
-    if constexpr (FT == 0) {
-      const uint32_t maxBlocks = grid.x * kDecBlocksPerTile;
-      auto launch = [&](auto geom, auto kernel, uint32_t wgPerCu) {
-        typedef decltype(geom) G;
-        const uint32_t roundsPerElem = divUp(maxBlocks, G::kRoundBlocks);
-        const uint64_t slots = (uint64_t)wgPerCu * numComputeUnits();
-        uint32_t rounds = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(roundsPerElem, (uint64_t)roundsPerElem * grid.y / slots));
-        while (rounds > 1u && roundsPerElem % rounds != 0u) --rounds;  // equal slices
-        const uint32_t sliceBlocks = rounds * G::kRoundBlocks;
-        DGPU_LAUNCH("k_ans_decode", stream, kernel, dim3(divUp(maxBlocks, sliceBlocks), grid.y), dim3(G::kThreads), G::ldsBytes(P), stream, a, sliceBlocks);
-      };
-      switch (decodeMtVariant()) {
-        case 2: launch(MtGeom<1, 2048, 8>(), (k_ans_decode_mt<P, 0, 1, 2048, 8>), 4); break;  // one chain, 2 KiB rings: k_ans_decode's geometry
-        case 3: launch(MtGeom<2, 2048, 4>(), (k_ans_decode_mt<P, 0, 2, 2048, 4>), 4); break;  // two chains, 2 KiB rings, 4 wavefronts
-        default: launch(MtGeom<2, 1024, 8>(), (k_ans_decode_mt<P, 0, 2, 1024, 8>), 4); break; // two chains, 1 KiB rings
-      }
-    }
-#endif
   } else {
-    // DGPU_DEC_LDS_PAD (experiment knob): extra dynamic LDS per workgroup, i.e. fewer workgroups per CU -- the
-    // occupancy scaling of the 16-block decoder (tools/occupancy_scaling.sh)
-    static const uint32_t pad = [] {
-      const char* e = getenv("DGPU_DEC_LDS_PAD");
-      return e ? (uint32_t)atoi(e) : 0u;
-    }();
     DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode<P, FT, kDecBlocksPerTile>), grid, dim3(kDecBlocksPerTile * 32u),
-                decLdsBytes(P, FT, kDecBlocksPerTile) + pad, stream, a);
+                decLdsBytes(P, FT, kDecBlocksPerTile), stream, a);
   }
   DGPU_HIP(hipGetLastError());
   return DGPU_OK;
@@ -1578,14 +1319,6 @@ uint32_t dgpu_last_checksum_mismatches(int32_t* batchIdx, uint32_t* expected, ui
   return n;
 }
 
-#ifdef DGPU_PHASE_TIMING
-// debug builds only: point the encode kernel's phase-timing hook at a device buffer
-int dgpu_debug_set_phase_buffer(void* buf_dev) {
-  DGPU_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_phaseBuf), &buf_dev, sizeof(void*)));
-  return DGPU_OK;
-}
-#endif
-
 static std::atomic<uint32_t> g_absentModulo{0};
 }  // extern "C"
 namespace {
@@ -1594,8 +1327,6 @@ uint32_t absentWorkgroupModulo() { return g_absentModulo.load(); }
 extern "C" {
 void dgpu_debug_set_absent_workgroups(uint32_t modulo) { g_absentModulo.store(modulo); }
 void dgpu_debug_set_param_cache(int on) { g_paramCacheEnabled.store(on != 0); }
-void dgpu_debug_set_fused(int mode) { g_fusedMode.store(mode < 0 ? -1 : (mode != 0)); }
-int dgpu_has_fused(void) { return DGPU_WITH_FUSED; }
 void dgpu_set_histogram_load_policy(int mode) { g_histLoadPolicy.store(mode < 0 ? -1 : (mode != 0)); }
 int dgpu_release_graph_state(void) {
   const int n = paramCache().releaseGraphPins();
@@ -1663,13 +1394,12 @@ uint32_t dgpu_float_max_compressed_size(uint32_t ft, uint32_t n) {
 
 static size_t encodeTempBytes(uint32_t B, uint32_t maxBytes, uint32_t wordBytes, bool spills) {
   size_t tiles = std::max(tilesFor(maxBytes), 1u);
-  size_t parts = std::max<size_t>(histPartsFor(B, maxBytes * wordBytes, true), std::min<size_t>(tiles, kFusedMaxTiles));
+  size_t parts = histPartsFor(B, maxBytes * wordBytes, true);
   size_t t = 0;
   t += alignUp((size_t)B * 4, kTempAlign);                                        // checksums
   t += alignUp((size_t)B * parts * kNumSymbols * 4, kTempAlign);                  // partial histograms
   t += alignUp((size_t)B * kNumSymbols * 16, kTempAlign);                         // encoder table
   t += alignUp((size_t)B * tiles * 8, kTempAlign);                                // tile descriptors
-  t += alignUp((size_t)64 * kTicketStride * 4, kTempAlign);                       // ticket counters
   t += alignUp((size_t)B * tiles * 4, kTempAlign);                                // tile claim words
   if (spills) {
     // spill slots of the persistent encoder workgroups (bounded by what fits on the chip)
@@ -1908,9 +1638,8 @@ int dgpu_float_compress_stride_capped(
   TempArena arena(temp_dev, tempBytes, streamLease);
   const BatchView in = viewStride(in_dev, inStrideBytes, inWords);
   const BatchView out = viewStride(out_dev, outStrideBytes, 0);
-  const bool aligned16 = ((uintptr_t)in_dev % 16) == 0 && (numInBatch <= 1 || inStrideBytes % 16 == 0);
-  int rc = encodeCommon(arena, streamLease, st, probBits, useChecksum != 0, numInBatch, in, out, floatType, inWords, inWords,
-                        aligned16, nullptr, outSize_dev, outCapacityBytes);
+  int rc = encodeCommon(arena, streamLease, st, probBits, useChecksum != 0, numInBatch, in, out, floatType, inWords, nullptr,
+                        outSize_dev, outCapacityBytes);
   if (tempUsed) *tempUsed = arena.requested();
   return rc;
 }
@@ -2096,10 +1825,8 @@ int dgpu_ans_calc_weights(
   n.floatUseChecksum = 0;
   n.tileDesc = nullptr;
   n.maxTiles = 0;
-  n.ticket = nullptr;
   n.claims = nullptr;
   n.numInBatch = numInBatch;
-  n.inKernelConsumer = 0;
   hipLaunchKernelGGL(k_normalize, dim3(numInBatch), dim3(256), 0, (hipStream_t)stream, n);
   DGPU_HIP(hipGetLastError());
   return DGPU_OK;

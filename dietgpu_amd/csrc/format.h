@@ -17,40 +17,27 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// Streaming (non-temporal) access helpers.  kNt selects the cache policy at the
-// call site; the DGPU_NT_* macros are the A/B knobs the defaults were chosen with
-// ("cache policy"; round 3 judged them on ROTATING buffers -- inputs, archives and outputs that
-// are not in the 256 MiB memory-side cache when their turn comes, as in real use -- not on a loop that re-codes
-// one buffer set):
-//   * decoded float words are written once and not read again by the codec: non-temporal stores
+// Streaming (non-temporal) access helpers and the cache policy of every stream the kernels touch.  The policies
+// were chosen on ROTATING buffers -- inputs, archives and outputs that are not in the 256 MiB memory-side cache when
+// their turn comes, as in real use -- not on a loop that re-codes one buffer set ("cache
+// policy"; profiles/r03_ab_cache_policy_*.txt, profiles/r03_rotating_phases.txt):
+//   * decoded float words are written once and not read again by the codec: non-temporal stores (1-byte
+//     non-temporal stores are slow, so decoded raw bytes use ordinary ones)
 //   * the encoder's input reads are a one-shot stream: non-temporal loads
 //   * the histogram pass reads with non-temporal loads too.  Its policy is the one knob that is also a RUN-TIME
 //     choice (dgpu_set_histogram_load_policy): with ORDINARY (allocating) loads the read-only histogram pass pushes
 //     the dirty lines earlier kernels left in the memory-side cache out while it has write bandwidth to spare, and the
 //     encoder then reads its input from that cache.  In a loop that compresses and at once decompresses on rotating
-//     buffers this is worth 9 % (bf16 0.2515 -> 0.228 ms per step: the decoder no longer waits for write-backs to make
-//     room for its own stores); in every arrangement that resembles use -- compress only, compress after a producer
-//     kernel has written the tensor, one buffer set -- it LOSES 4-20 % (the histogram takes 52-72 us instead of 46-52),
-//     so it is not the default ("cache policy"; profiles/r03_ab_cache_policy_*.txt,
-//     profiles/r03_rotating_phases.txt)
-//   * archive stores stay cacheable: the consumer (decode, a send) follows soon
-#ifndef DGPU_NT_DEC_STORES
-#define DGPU_NT_DEC_STORES 1
-#endif
-#ifndef DGPU_NT_ENC_STORES
-#define DGPU_NT_ENC_STORES 0
-#endif
-#ifndef DGPU_NT_HIST_LOADS
-#define DGPU_NT_HIST_LOADS 1
-#endif
-#ifndef DGPU_NT_HIST_LOADS_F16
-#define DGPU_NT_HIST_LOADS_F16 1
-#endif
-#ifndef DGPU_NT_ENC_LOADS
-#define DGPU_NT_ENC_LOADS 1
-#endif
-
+//     buffers this is worth 9 %; in every arrangement that resembles use -- compress only, compress after a producer
+//     kernel has written the tensor, one buffer set -- it LOSES 4-20 %, so it is not the default
+//   * archive stores and the decoder's archive loads stay cacheable: the consumer (decode, a send) follows soon
 namespace dgpu {
+
+constexpr bool kNtDecStores = true;
+constexpr bool kNtEncStores = false;
+constexpr bool kNtEncLoads = true;
+constexpr bool kNtDecLoads = false;
+constexpr bool kNtHistLoads = true;  // default; dgpu_set_histogram_load_policy overrides it at run time
 
 typedef uint32_t dgpu_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -89,10 +76,6 @@ constexpr uint32_t kFloatVersion = 0x0001u;
 constexpr uint32_t kBlockAlignWords = 8;   // 16 bytes of u16
 
 constexpr uint32_t kFloat16 = 1, kBFloat16 = 2, kFloat32 = 3;
-// default cache policy of the histogram pass's input loads, by input type (see the top of this file)
-__host__ __device__ constexpr bool histLoadsNonTemporal(uint32_t ft) {
-  return (ft == kFloat16 || ft == kBFloat16) ? (DGPU_NT_HIST_LOADS_F16 != 0) : (DGPU_NT_HIST_LOADS != 0);
-}
 
 // Blocks handled by one 256-thread workgroup: 4 wave64 x 2 half-waves.
 constexpr uint32_t kBlocksPerTile = 8;

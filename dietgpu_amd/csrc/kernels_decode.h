@@ -66,30 +66,20 @@ __device__ __forceinline__ uint64_t decodeInBytes(const DecodeArgs& a, uint32_t 
 // (GpuFloatUtils.cuh:117-119,149-159,187-190) arranged so that the result sits
 // in the TOP half of a register and is stored with a d16_hi short store; the
 // pdf bits that ride along in the low 12 bits never reach the stored half.
-// Wide-store variant of the write-out (DGPU_DEC_WIDE_STORES): the row loop keeps one 2-byte (1-byte) store
-// per lane per row otherwise -- 64-byte (32-byte) pieces per half-wave, which the memory system turns into
-// 1.3x the bytes (WRITE_SIZE, profiles/).  With it, the 8 rows of a group are transposed through a 512-byte
-// (256-byte) LDS buffer per block and leave as ONE 16-byte (8-byte) store per lane: 512 (256) contiguous bytes.
-// Measured (profiles/r02_*): bf16 P=10 decode 100 -> 86 us on its own, step 243 -> 236 us, WRITE_SIZE back to
-// the algorithmic bytes.  At P = 11 the 16 KiB LUT + rings + buffers would leave 2 workgroups per CU
-// (fp16 P=11: +5 us), so the narrow stores stay there; fp32 rows are 128-byte pieces already.
-#ifndef DGPU_DEC_WIDE_STORES
-#define DGPU_DEC_WIDE_STORES 1
-#endif
-// DGPU_NT_DEC_LOADS: the decoder's reads of the archive (non-compressed bytes, compressed words) as non-temporal
-// (streaming) loads -- an A/B knob of the cache-policy study (rotating buffers)
-#ifndef DGPU_NT_DEC_LOADS
-#define DGPU_NT_DEC_LOADS 0
-#endif
+// Wide stores: with one 2-byte (1-byte) store per lane and row a half-wave writes 64-byte (32-byte) pieces, which
+// the memory system turns into 1.3x the bytes (WRITE_SIZE, profiles/r02_write_calib.txt).  Instead the 8 rows of a
+// group are transposed through a 512-byte LDS buffer per block and leave as ONE 16-byte (8-byte) store per lane:
+// 512 (256) contiguous bytes (bf16 P=10 decode 100 -> 86 us, WRITE_SIZE back to the algorithmic bytes).  fp32 rows
+// are 128-byte pieces already; raw bytes in 16-block tiles keep the narrow stores (decXposeBytes).
 __device__ __forceinline__ uint2 decLoad8(const uint8_t* p) {
   typedef uint32_t u32x2n __attribute__((ext_vector_type(2)));
-  if (DGPU_NT_DEC_LOADS) {
+  if (kNtDecLoads) {
     const u32x2n v = __builtin_nontemporal_load((const u32x2n*)p);
     return make_uint2(v.x, v.y);
   }
   return *(const uint2*)p;
 }
-__device__ __forceinline__ uint4 decLoad16(const uint8_t* p) { return streamLoad<DGPU_NT_DEC_LOADS != 0>((const uint4*)p); }
+__device__ __forceinline__ uint4 decLoad16(const uint8_t* p) { return streamLoad<kNtDecLoads>((const uint4*)p); }
 typedef __attribute__((address_space(3))) uint16_t LdsU16w;
 typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4w LdsU4w;
@@ -97,13 +87,7 @@ typedef __attribute__((address_space(3))) u32x4w LdsU4w;
 // Per-row join (narrow path): {e0.b3 (symbol), r.b0 (non-compressed byte), e0.b1, e0.b0} in one v_perm_b32.
 // (The byte loaded a group earlier still costs one v_and per row here: it crosses the loop edge as an i8 and the
 // compiler sinks its zero-extension away from the load.  The wide path has no per-row byte at all.)
-#ifndef DGPU_DEC_PERM_JOIN
-#define DGPU_DEC_PERM_JOIN 1
-#endif
-__device__ __forceinline__ uint32_t joinBytes(uint32_t e0, uint32_t r) {
-  if (DGPU_DEC_PERM_JOIN) return __builtin_amdgcn_perm(e0, r, 0x07000504u);
-  return (r << 16) | e0;
-}
+__device__ __forceinline__ uint32_t joinBytes(uint32_t e0, uint32_t r) { return __builtin_amdgcn_perm(e0, r, 0x07000504u); }
 
 template <uint32_t FT>
 struct RowSink;
@@ -148,7 +132,7 @@ struct RowSink<kFloat16> {  // word = comp << 8 | nonComp
   __device__ __forceinline__ uint32_t prefetch(uint32_t row) const { return nc[row * 32u]; }
   __device__ __forceinline__ void store(uint32_t row, uint32_t e0, uint32_t r) const {
     const uint32_t v = joinBytes(e0, r);  // [sym][nc][0000 pdf]
-    streamStore<DGPU_NT_DEC_STORES != 0>(&out[row * 32u], (uint16_t)(v >> 16));
+    streamStore<kNtDecStores>(&out[row * 32u], (uint16_t)(v >> 16));
   }
   // wide variant (see decodeBlock): rows stage {sym, 0}; a lane joins its 8 consecutive words with the 8
   // non-compressed bytes it loaded with ONE 8-byte load: one v_perm_b32 per pair of words
@@ -165,7 +149,7 @@ struct RowSink<kFloat16> {  // word = comp << 8 | nonComp
     o.z = __builtin_amdgcn_perm(v.z, ncb.y, 0x07010500u);
     o.w = __builtin_amdgcn_perm(v.w, ncb.y, 0x07030502u);
     u32x4w* dst = (u32x4w*)(out - hl + g * 256u + hl * 8u);
-    if (DGPU_NT_DEC_STORES) __builtin_nontemporal_store(o, dst);
+    if (kNtDecStores) __builtin_nontemporal_store(o, dst);
     else *dst = o;
   }
 };
@@ -183,7 +167,7 @@ struct RowSink<kBFloat16> {  // word = (comp << 8 | nonComp) >> 1 | (nonComp & 1
   __device__ __forceinline__ void store(uint32_t row, uint32_t e0, uint32_t r) const {
     const uint32_t lo = joinBytes(e0, r);                                 // [sym][nc][0000 pdf]
     const uint32_t v = __builtin_amdgcn_alignbit(r, lo, 1);     // (lo >> 1) | (r << 31)
-    streamStore<DGPU_NT_DEC_STORES != 0>(&out[row * 32u], (uint16_t)(v >> 16));                    // [sign][exp][mant7]
+    streamStore<kNtDecStores>(&out[row * 32u], (uint16_t)(v >> 16));                    // [sign][exp][mant7]
   }
   // wide variant: as fp16, then every 16-bit half {exp, nc} rotated right by one (sign to the top):
   // (h >> 1) + h * 2^15 on packed halves (v_pk_lshrrev_b16 + v_pk_mad_u16)
@@ -208,7 +192,7 @@ struct RowSink<kBFloat16> {  // word = (comp << 8 | nonComp) >> 1 | (nonComp & 1
     o.z = rotrHalves(__builtin_amdgcn_perm(v.z, ncb.y, 0x07010500u));
     o.w = rotrHalves(__builtin_amdgcn_perm(v.w, ncb.y, 0x07030502u));
     u32x4w* dst = (u32x4w*)(out - hl + g * 256u + hl * 8u);
-    if (DGPU_NT_DEC_STORES) __builtin_nontemporal_store(o, dst);
+    if (kNtDecStores) __builtin_nontemporal_store(o, dst);
     else *dst = o;
   }
 };
@@ -229,7 +213,7 @@ struct RowSink<kFloat32> {  // rotr32(comp << 24 | nonComp24, 1)
   }
   __device__ __forceinline__ void store(uint32_t row, uint32_t e0, uint32_t r) const {
     const uint32_t v = (e0 & 0xff000000u) | r;
-    streamStore<DGPU_NT_DEC_STORES != 0>(&out[row * 32u], (uint32_t)__builtin_amdgcn_alignbit(v, v, 1));
+    streamStore<kNtDecStores>(&out[row * 32u], (uint32_t)__builtin_amdgcn_alignbit(v, v, 1));
   }
   static constexpr uint32_t kXposeBytes = 0;  // 128-byte row pieces already: no transposition
   __device__ __forceinline__ uint2 prefetchGroup(uint32_t, uint32_t) const { return make_uint2(0, 0); }
@@ -263,39 +247,28 @@ constexpr uint32_t kDecBlocksPerTile = 16;
 constexpr uint32_t kDecBlocksPerSmallTile = 4;
 // ... and one wavefront per element for batches of elements of at most 2 blocks
 constexpr uint32_t kDecBlocksPerTinyTile = 2;
-// ... and one ring + one store buffer for batches of single-block elements (the idle upper half of the wave
-// touches neither): 6.5 KiB per workgroup at probBits 10
+// ... and batches of single-block elements (every capacity <= 4096 symbols) go to k_ans_decode_pair
+// (kernels_pairs.h): two ELEMENTS per wavefront
 constexpr uint32_t kDecBlocksPerSingleTile = 1;
 __host__ __device__ constexpr uint32_t decThreads(uint32_t tileBlocks) { return tileBlocks * 32u < 64u ? 64u : tileBlocks * 32u; }
-// probBits 11: the LUT has 2048 slots; with the COMPACT 4-byte entries (below) it takes the 8 KiB the 8-byte
-// entries take at probBits 10, which leaves room for the store buffers at the same 3 workgroups per CU.
-#ifndef DGPU_DEC_COMPACT_P11
-#define DGPU_DEC_COMPACT_P11 1
-#endif
-// Raw bytes in 16-block tiles keep the narrow stores (DGPU_DEC_RAW_WIDE16 = 0): their row loop is bound by the
-// latency of its dependent chain (two LDS round trips per row), not by the stores or by instruction issue --
-// four extra s_nop per row cost 0.6 %, four extra VALU moves 2.5 % (tools/issue_model.sh) -- so a fourth
-// workgroup per CU (40 KiB instead of 48: 8 waves per SIMD) is worth more than the 8-byte stores:
-// 256 x 1 MiB Zipf bytes decode 152.5 -> 145 us.  (16-bit floats are HBM-bound with the wide stores, and their
-// narrow 2-byte non-temporal stores inflate the write traffic by 1.35, section 4.2 of DESIGN.md.)
-#ifndef DGPU_DEC_RAW_WIDE16
-#define DGPU_DEC_RAW_WIDE16 0
-#endif
+// Store (transposition) buffers per block.  Raw bytes in 16-block tiles keep the narrow stores: a fourth
+// workgroup per CU (40 KiB instead of 48: 8 waves per SIMD) is worth more to their row loop than the 8-byte
+// stores (256 x 1 MiB Zipf bytes decode 152.5 -> 145 us).  16-bit floats are HBM-bound with the wide stores, and
+// their narrow 2-byte non-temporal stores inflate the write traffic by 1.35.
 __host__ __device__ constexpr uint32_t decXposeBytes(int P, uint32_t ft, uint32_t tileBlocks) {
-  if (ft == 0 && tileBlocks >= 16u && !DGPU_DEC_RAW_WIDE16) return 0u;
-  return (DGPU_DEC_WIDE_STORES && (P <= 10 || DGPU_DEC_COMPACT_P11)) ? (ft == kFloat32 ? 0u : 512u) : 0u;
+  (void)P;
+  if (ft == 0 && tileBlocks >= 16u) return 0u;
+  return ft == kFloat32 ? 0u : 512u;
 }
 // COMPACT LUT entries, 4 bytes {sym:8 | x - cdf:12 | pdf:12} instead of 8 (two more VALU per row to unpack):
 //  * tiles of <= 4 blocks (batches of small elements): residency there is set by the LDS a workgroup needs for
 //    its own LUT (measured on 32768 x 4 Ki: decode 228 / 323 / 476 us with a 4 / 8 / 16 KiB LUT; 8192 x 16 Ki:
 //    139 -> 133 us), and a lone, latency-bound wavefront does not feel the unpacking;
-//  * probBits 11 (any tile): see decXposeBytes.
-#ifndef DGPU_DEC_COMPACT_MAX_TILE
-#define DGPU_DEC_COMPACT_MAX_TILE 4
-#endif
-__host__ __device__ constexpr bool decCompactLut(int P, uint32_t tileBlocks) {
-  return tileBlocks <= DGPU_DEC_COMPACT_MAX_TILE || (DGPU_DEC_COMPACT_P11 && P >= 11);
-}
+//  * probBits 11 (any tile): the LUT has 2048 slots; compact, it takes the 8 KiB the 8-byte entries take at
+//    probBits 10, which leaves room for the store buffers at the same 3 workgroups per CU (fp16 P=11 decode
+//    105.5 -> 97.9 us).  At probBits 10 in 16-block tiles the compact entry is SLOWER (+4 .. +9 us on Zipf bytes):
+//    its unpacking sits on the dependent chain.
+__host__ __device__ constexpr bool decCompactLut(int P, uint32_t tileBlocks) { return tileBlocks <= 4u || P >= 11; }
 __host__ __device__ constexpr uint32_t decLutBytes(int P, uint32_t tileBlocks) {
   return decCompactLut(P, tileBlocks) ? (4u << P) : (8u << P);
 }
@@ -307,7 +280,7 @@ __host__ __device__ constexpr uint32_t decLdsBytes(int P, uint32_t ft, uint32_t 
 // it has a single block): its lanes run the same straight-line code on don't-care data and only their
 // stores are suppressed, so the lower half keeps the fast path instead of the predicated one.
 //
-// Position tracking (kFull, DGPU_DEC_SCALAR_POS): the unread-word counts of the two halves are wave-uniform, so
+// Position tracking (kFull): the unread-word counts of the two halves are wave-uniform, so
 // they live in two SGPRs (s_bcnt1 of the ballot halves); a reading lane's word index comes from
 // v_mbcnt_lo + v_mbcnt_hi over the 64-bit ballot (lower half: its rank; upper half: rank + readers of the lower
 // half) plus one v_mad_i32_i24 that moves the upper half onto its own position: 4-5 VALU per row where the
@@ -316,12 +289,6 @@ __host__ __device__ constexpr uint32_t decLdsBytes(int P, uint32_t ft, uint32_t 
 // kNoRing (kFull): both blocks of the wave have <= 1024 compressed words (every exponent block of N(0,1)
 // bf16 has ~650), so the whole block is staged once and the ring maintenance, the wrap mask and the base OR
 // disappear from the row loop (the base is folded into the scalar positions).
-#ifndef DGPU_DEC_SCALAR_POS
-#define DGPU_DEC_SCALAR_POS 1
-#endif
-#ifndef DGPU_DEC_NORING
-#define DGPU_DEC_NORING 1
-#endif
 template <int P, uint32_t FT, bool kFull, bool kWide = false, bool kIdleUpper = false, bool kCompact = false, bool kNoRing = false>
 __device__ __forceinline__ void decodeBlock(
     uint32_t xpose,                // kWide: LDS address of this half's transposition buffer
@@ -405,7 +372,7 @@ __device__ __forceinline__ void decodeBlock(
   // lanes that need to renormalise keep it.
   // wave-uniform positions (SGPRs): unread words of the lower / upper half's block; kNoRing: plus the LDS word
   // address of the block's staging area, so that (position + rank) << 1 IS the LDS address
-  constexpr bool kScalarPos = kFull && (DGPU_DEC_SCALAR_POS || kNoRing);
+  constexpr bool kScalarPos = kFull;
   uint32_t sLo = 0, sHi = 0;
   if (kScalarPos) {
     sLo = __builtin_amdgcn_readlane(numWords, 0);
@@ -417,42 +384,23 @@ __device__ __forceinline__ void decodeBlock(
   }
   // an idle upper half follows the lower half's addresses (in bounds; its words are never used)
   int upperSel = (upper && !kIdleUpper) ? 1 : 0;
-#ifdef DGPU_DEC_PAD_VALU
-  uint32_t padReg = hl;
-#endif
   asm volatile("" : "+v"(upperSel));  // a VGPR operand of the multiply-add, not a select to be folded into it
   auto stepFull = [&]() -> uint32_t {
     const uint2 e = lutAt(state & kMask);
     state = __umul24(e.x, state >> P) + e.y;
     const bool read = state < kMinState;
     const uint64_t vote = __ballot(read);
-#ifdef DGPU_DEC_PAD_SNOP  // issue-model experiment (tools/issue_model.sh): N extra scalar no-ops per row
-#pragma unroll
-    for (int i = 0; i < DGPU_DEC_PAD_SNOP; ++i) asm volatile("s_nop 0");
-#endif
-#ifdef DGPU_DEC_PAD_VALU  // ... or N extra independent VALU moves per row
-#pragma unroll
-    for (int i = 0; i < DGPU_DEC_PAD_VALU; ++i) asm volatile("v_mov_b32 %0, %0" : "+v"(padReg));
-#endif
-    if (kScalarPos) {
-      const uint32_t vLo = (uint32_t)vote, vHi = (uint32_t)(vote >> 32);
-      const uint32_t sLoOld = sLo;
-      sLo -= (uint32_t)__popc(vLo);
-      sHi -= (uint32_t)__popc(vHi);
-      // readers below me in the wave: lower half = my rank, upper half = rank + readers of the lower half
-      uint32_t t = __builtin_amdgcn_mbcnt_hi(vHi, __builtin_amdgcn_mbcnt_lo(vLo, 0u));
-      // lower: sLo + rank; upper: sHi + rank = sLo + (rank + readersLo) + (sHi - sLoOld)
-      t = (uint32_t)(__mul24(upperSel, (int)(sHi - sLoOld)) + (int)t);
-      asm volatile("" : "+v"(t));  // keep the scalar position in the add-shift below (one SGPR operand per VALU op)
-      const uint32_t addr = kNoRing ? ((t + sLo) << 1) : ((((t + sLo) << 1) & (kRingBytes - 1u)) | ringBase);
-      const uint32_t w = *(const LdsU16*)(uintptr_t)addr;
-      state = read ? ((state << kEncodedBits) | w) : state;
-      return e.x;
-    }
-    const uint32_t vh = upper ? (uint32_t)(vote >> 32) : (uint32_t)vote;
-    posw -= __popc(vh);
-    const uint32_t idx = posw + __popc(vh & laneMaskLt);
-    const uint32_t w = *(const LdsU16*)(uintptr_t)(((idx << 1) & (kRingBytes - 1u)) | ringBase);
+    const uint32_t vLo = (uint32_t)vote, vHi = (uint32_t)(vote >> 32);
+    const uint32_t sLoOld = sLo;
+    sLo -= (uint32_t)__popc(vLo);
+    sHi -= (uint32_t)__popc(vHi);
+    // readers below me in the wave: lower half = my rank, upper half = rank + readers of the lower half
+    uint32_t t = __builtin_amdgcn_mbcnt_hi(vHi, __builtin_amdgcn_mbcnt_lo(vLo, 0u));
+    // lower: sLo + rank; upper: sHi + rank = sLo + (rank + readersLo) + (sHi - sLoOld)
+    t = (uint32_t)(__mul24(upperSel, (int)(sHi - sLoOld)) + (int)t);
+    asm volatile("" : "+v"(t));  // keep the scalar position in the add-shift below (one SGPR operand per VALU op)
+    const uint32_t addr = kNoRing ? ((t + sLo) << 1) : ((((t + sLo) << 1) & (kRingBytes - 1u)) | ringBase);
+    const uint32_t w = *(const LdsU16*)(uintptr_t)addr;
     state = read ? ((state << kEncodedBits) | w) : state;
     return e.x;
   };
@@ -759,7 +707,7 @@ __global__ __launch_bounds__(decThreads(kTileBlocks)) void k_ans_decode(DecodeAr
   // both blocks of the wave small enough to be staged whole (wave-uniform)?
   const uint32_t wFirst = __shfl(numWords, 0, 64);
   const uint32_t wSecond = __shfl(numWords, 32, 64);
-  const bool noRing = DGPU_DEC_NORING && wFirst <= kRingBytes / 2u && wSecond <= kRingBytes / 2u;
+  const bool noRing = wFirst <= kRingBytes / 2u && wSecond <= kRingBytes / 2u;
 #define DGPU_DECODE_FULL(WIDE, IDLE, NORING) \
   decodeBlock<P, FT, true, WIDE, IDLE, kCompact, NORING>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + slot * kRingBytes, sLut, sink, hl, upper)
   if (nFirst == kBlockSize && nSecond == kBlockSize) {

@@ -44,9 +44,9 @@ __device__ __forceinline__ uint32_t halfInclusiveMaxScanDpp(uint32_t v) {
 __device__ __forceinline__ void pairLdsFence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // ---------------------------------------------------------------------------
-// Encoder.  LDS: two 4 KiB tables, two stages, two 512-byte symbol rings, 128 bytes of scratch slots.
+// Encoder.  LDS: two 4 KiB tables, two stages, two 512-byte symbol rings.
 __host__ __device__ constexpr uint32_t encPairLdsBytes(int P, bool spill, uint32_t ft) {
-  return 2u * 4096u + 2u * encStageCap(P, spill, ft) * 2u + 2u * 512u + 128u;
+  return 2u * 4096u + 2u * encStageCap(P, spill, ft) * 2u + 2u * 512u;
 }
 
 // Persistent: workgroup w encodes the pairs w, w + G, ...; a.spill holds [gridDim.x][2][encSpillSlotWords(P)].
@@ -65,8 +65,6 @@ __global__ __launch_bounds__(64) void k_ans_encode_pair(EncodeArgs a) {
   uint8_t* ring = smem + 8192u + 4u * kCap + half * 512u;
   const uint32_t tableLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)sTable;
   const uint32_t stageLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)stage;
-  const uint32_t dummyLds =
-      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(smem + 8192u + 4u * kCap + 1024u) + lane * 2u;
   uint16_t* spillSlot = kSpill ? a.spill + ((size_t)blockIdx.x * 2u + half) * encSpillSlotWords(P) : nullptr;
 
   const uint32_t B = a.numInBatch;
@@ -122,15 +120,15 @@ __global__ __launch_bounds__(64) void k_ans_encode_pair(EncodeArgs a) {
     uint32_t state;
     uint32_t words;
     uint32_t spilled = 0;
+    bool overrun = false;  // see encodeRows: only with a caller-supplied histogram that does not cover the data
     if (bothFull) {
-      words = encodeRows<P, FT, true, kSpill>(src, n, kRowsPerBlock, sTable, tableLds, stageLds, dummyLds, ring, hl, upper,
-                                              spillSlot, spilled, state);
+      words = encodeRows<P, FT, true, kSpill>(src, n, kRowsPerBlock, tableLds, stageLds, ring, hl, upper, spillSlot, spilled,
+                                              state, overrun);
     } else {
       const uint32_t nMax = sLo > sHi ? sLo : sHi;
-      words = encodeRows<P, FT, false, kSpill>(src, n, divUp(nMax, 32u), sTable, tableLds, stageLds, dummyLds, nullptr, hl,
-                                               upper, spillSlot, spilled, state);
+      words = encodeRows<P, FT, false, kSpill>(src, n, divUp(nMax, 32u), tableLds, stageLds, nullptr, hl, upper, spillSlot,
+                                               spilled, state, overrun);
     }
-    if (!kSpill) words = words < kCap ? words : kCap;
     pairLdsFence();  // stage complete
 
     if (have) {
@@ -143,8 +141,9 @@ __global__ __launch_bounds__(64) void k_ans_encode_pair(EncodeArgs a) {
       const uint32_t totalPadded = spilled + padded;
       if (hl == 0) {
         // complete the header (GpuANSEncode.cuh:533-566) and the block descriptors (:595-608): one block at offset 0
-        ((AnsHeader*)ans)->totalCompressedWords = totalPadded;
-        if (a.outSize) a.outSize[b] = ansOffsetInArchive(FT, n) + ansOverhead(1u) + 2u * totalPadded;
+        ((AnsHeader*)ans)->totalCompressedWords = overrun ? 0u : totalPadded;
+        if (overrun) ((AnsHeader*)ans)->magicAndVersion = 0u;  // failed element: no decoder will follow this archive
+        if (a.outSize) a.outSize[b] = overrun ? 0u : ansOffsetInArchive(FT, n) + ansOverhead(1u) + 2u * totalPadded;
         uint2* blockWords = (uint2*)(ans + ansBlockWordsOffset(1u));
         blockWords[0] = make_uint2((n << 16) | total, 0u);
         blockWords[1] = make_uint2(0u, 0u);  // alignment pad entry
@@ -158,12 +157,12 @@ __global__ __launch_bounds__(64) void k_ans_encode_pair(EncodeArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint4* sp = (const uint4*)spillSlot;
         const uint32_t sv = spilled / kBlockAlignWords;
-        for (uint32_t i = hl; i < sv; i += 32u) streamStore<DGPU_NT_ENC_STORES != 0>(&dst[i], sp[i]);
+        for (uint32_t i = hl; i < sv; i += 32u) streamStore<kNtEncStores>(&dst[i], sp[i]);
         dst += sv;
       }
       const uint32_t vecs = roundUp(words, kBlockAlignWords) / kBlockAlignWords;
       const uint4* s4 = (const uint4*)stage;
-      for (uint32_t i = hl; i < vecs; i += 32u) streamStore<DGPU_NT_ENC_STORES != 0>(&dst[i], s4[i]);
+      for (uint32_t i = hl; i < vecs; i += 32u) streamStore<kNtEncStores>(&dst[i], s4[i]);
     }
     pairLdsFence();  // the next pair overwrites tables and stages
   }

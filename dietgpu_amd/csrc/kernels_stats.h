@@ -83,13 +83,8 @@ struct NormalizeArgs {
   // encode hand-off state cleared here for the encode kernel that follows on the stream
   uint64_t* tileDesc;        // [B][maxTiles] nullable
   uint32_t maxTiles;
-  uint32_t* ticket;          // nullable
   uint32_t* claims;          // [maxTiles][numInBatch] nullable (encoder's tile claim words)
   uint32_t numInBatch;
-  // != 0: called from inside the fused encode kernel (k_ans_encode_fused).  The table is read by other
-  // workgroups of the SAME kernel, possibly on other XCDs: it is stored write-through; and the header word
-  // `totalCompressedWords` is left to the element's last tile (two XCDs must not hold the same bytes dirty).
-  uint32_t inKernelConsumer;
 };
 
 // One 256-thread workgroup normalises batch element b.  kCoherent: the partial
@@ -123,7 +118,6 @@ __device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const u
       a.tileDesc[(size_t)b * a.maxTiles + i] = 0;
       if (a.claims) a.claims[(size_t)i * a.numInBatch + b] = 0;
     }
-    if (b == 0 && tid < 64u) a.ticket[tid * 32u] = 0;  // the encoder's ticket counters (<= 64, 32 words apart)
   }
 
   if (total != 0) {
@@ -279,13 +273,7 @@ __device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const u
     e.y = m;
     e.z = cdfTerm;
     e.w = ((W - pdf) & 0xffffffu) | (sh << 24);
-    if (a.inKernelConsumer) {
-      uint64_t* dst = (uint64_t*)&a.encTable[b * kNumSymbols + tid];
-      __hip_atomic_store(dst, (uint64_t)e.x | ((uint64_t)e.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(dst + 1, (uint64_t)e.z | ((uint64_t)e.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      a.encTable[b * kNumSymbols + tid] = e;
-    }
+    a.encTable[b * kNumSymbols + tid] = e;
   }
   if (a.refTable) {
     // the reference's table (pdf, cdf, 33-bit magic, shift), :349-358
@@ -312,16 +300,7 @@ __device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const u
       h.checksum = (a.useChecksum && a.checksum) ? a.checksum[b] : 0u;
       h.unused0 = 0;
       h.unused1 = 0;
-      if (a.inKernelConsumer && nb != 0) {
-        // every word but totalCompressedWords (written by the last tile, maybe from another XCD)
-        uint32_t* hw = (uint32_t*)ans;
-        hw[0] = h.magicAndVersion;
-        hw[1] = h.numBlocks;
-        hw[2] = h.totalUncompressedWords;
-        *(uint4*)(hw + 4) = make_uint4(h.options, h.checksum, 0u, 0u);
-      } else {
-        *(AnsHeader*)ans = h;
-      }
+      *(AnsHeader*)ans = h;
       if (nb == 0) {
         // empty element: no encode tile will run for it
         if (a.outSize) a.outSize[b] = ansOffsetInArchive(a.floatType, total) + ansOverhead(0);

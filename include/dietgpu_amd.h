@@ -315,15 +315,6 @@ void dgpu_debug_set_absent_workgroups(uint32_t modulo);
  * steady-state one. */
 void dgpu_debug_set_param_cache(int on);
 
-/* Test hook of the single-read encoder (k_ans_encode_fused), which only builds made with
- * -DDGPU_WITH_FUSED=1 contain (dgpu_has_fused() == 1; the default library does not: the kernel measured slower
- * than the two-kernel path).  There, uniform batches (every element the same whole number of 32 Ki-symbol tiles,
- * <= 32 of them, 16-byte aligned inputs, no caller histogram) can be encoded by ONE kernel that reads the input
- * once.  0 forces the two-kernel path, 1 the fused one where eligible, -1 restores the default (off unless the
- * environment has DGPU_FUSED=1).  Archives are byte-identical either way.  A no-op without the kernel. */
-void dgpu_debug_set_fused(int mode);
-int dgpu_has_fused(void);
-
 /* Cache policy of the encoder's histogram pass (its first kernel; the second reads the same input again): 0 = the
  * input is read with non-temporal loads (default), 1 = with ordinary loads, which allocate in the 256 MiB memory-side
  * cache -- the pass then also pays for evicting whatever dirty lines sit there and the encode kernel reads its input

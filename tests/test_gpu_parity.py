@@ -1287,9 +1287,11 @@ def test_large_single_element(dg):
 
 
 # ---------------------------------------------------------------------------
-# k_ans_decode_mt (raw bytes, elements of more than 8 blocks): four blocks per wavefront, 1 KiB word rings with
-# 128-word chunks refilled every four rows, element slices per workgroup.
-def _mt_block(rng, kind):
+# The decoder's word ring on raw-byte elements of more than 8 blocks: every block-kind mix inside a wavefront pair,
+# word counts on both sides of the ring's chunk boundaries, element tails, ragged batches, corrupt tables and
+# states.  (Written for the round-3 four-blocks-per-wavefront experiment, tools/experiments/round3_tree/; they
+# are the densest coverage the shipped k_ans_decode's ring / whole-block staging protocol has.)
+def _ring_block(rng, kind):
     if kind == "z":   # one symbol only: pdf = 2^P, the block emits no words at all
         return np.full(4096, 7, np.uint8)
     if kind == "c":   # ~1.2 bits per symbol: ~310 words, within the first three chunks
@@ -1300,7 +1302,7 @@ def _mt_block(rng, kind):
 
 
 @pytest.mark.parametrize("prob_bits", [9, 10, 11])
-def test_decode_mt_block_mixes(dg, prob_bits):
+def test_decode_ring_block_mixes(dg, prob_bits):
     # every combination of block kinds inside a quad, quads that mix full and partial blocks, element tails of
     # 1 / 2 / 3 blocks + a partial block, an element of exactly 9 blocks (two full quads + one block)
     rng = np.random.default_rng(777 + prob_bits)
@@ -1308,7 +1310,7 @@ def test_decode_mt_block_mixes(dg, prob_bits):
     tails = [0, 1, 4095, 33, 2049, 0]
     xs = []
     for p, t in zip(pats, tails):
-        parts = [_mt_block(rng, k) for k in p]
+        parts = [_ring_block(rng, k) for k in p]
         if t:
             parts.append(rng.integers(0, 256, t, dtype=np.uint8))
         xs.append(np.concatenate(parts))
@@ -1322,7 +1324,7 @@ def test_decode_mt_block_mixes(dg, prob_bits):
         assert (o == x).all(), (i, int(np.flatnonzero(o != x)[0]))
 
 
-def test_decode_mt_chunk_boundaries(dg):
+def test_decode_ring_chunk_boundaries(dg):
     # blocks whose compressed word counts sit on both sides of every chunk boundary of the 1 KiB ring protocol
     # (128-word chunks: 127 .. 129, 255 .. 257, 383 .. 385, 511 .. 513, ...), found by searching symbol mixes
     rng = np.random.default_rng(31337)
@@ -1350,7 +1352,7 @@ def test_decode_mt_chunk_boundaries(dg):
     assert status.all() and (outs[0] == x).all()
 
 
-def test_decode_mt_slices_and_batches(dg):
+def test_decode_ring_slices_and_batches(dg):
     # ragged batch: elements of 9 .. 300 blocks next to tiny ones (the grid is laid out for the largest capacity;
     # slices beyond an element's end and whole absent slices must do nothing), capacity larger than the size
     rng = np.random.default_rng(2024)
@@ -1366,9 +1368,9 @@ def test_decode_mt_slices_and_batches(dg):
         assert (o[: x.size] == x).all()
 
 
-def test_decode_mt_rejects_malformed_archives(dg):
-    # the checks of test_decoder_rejects_malformed_ans_archives on an element large enough for k_ans_decode_mt
-    # (40 blocks: two slices' worth of quads), corruptions in the middle of the block table included
+def test_decode_ring_rejects_malformed_archives(dg):
+    # the checks of test_decoder_rejects_malformed_ans_archives on an element of several 16-block tiles
+    # (40 blocks), corruptions in the middle of the block table included
     x = refgen.generate_symbols(39 * 4096 + 100, 20.0)
     good = O.ans_encode(x, 10)
     ref = torch.from_numpy(x).to(DEV)

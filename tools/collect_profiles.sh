@@ -6,7 +6,7 @@ strip() { grep -a -v "amdgpu.ids\|^RCCL version\|^HIP version\|^ROCm version\|^H
 for f in gpurun_out/${T}_bench_*.json gpurun_out/${T}_reference_protocol.json; do
   [ -f "$f" ] && strip "$f" | grep -a "^{" | tail -1 > profiles/$(basename $f)
 done
-for f in api_rate graph_rate rotating_phases pytest pytest_fused_build pytest_decode_mt_build; do
+for f in api_rate graph_rate rotating_phases pytest; do
   [ -f gpurun_out/${T}_$f.txt ] && strip gpurun_out/${T}_$f.txt > profiles/${T}_$f.txt
 done
 for w in bf16 u8 fp16 fp32; do

@@ -6,10 +6,6 @@ T=${1:-r03}
 mkdir -p gpurun_out
 ( timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 ) > gpurun_out/${T}_pytest.txt
 tail -3 gpurun_out/${T}_pytest.txt
-# the two experimental kernels on their own builds (tools/build_variant.py fused -DDGPU_WITH_FUSED=1 / mt -DDGPU_WITH_DEC_MT=1)
-[ -f dietgpu_amd/lib/v_fused.so ] && ( DGPU_LIB=$PWD/dietgpu_amd/lib/v_fused.so timeout 600 python -m pytest tests/test_gpu_fused.py -m gpu -x -q 2>&1 | tail -2 ) > gpurun_out/${T}_pytest_fused_build.txt
-[ -f dietgpu_amd/lib/v_mt.so ] && ( DGPU_LIB=$PWD/dietgpu_amd/lib/v_mt.so DGPU_DEC_MT=1 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "decode_mt or ans_ or config2 or fuzz or staging or rejects" 2>&1 | tail -2 ) > gpurun_out/${T}_pytest_decode_mt_build.txt
-cat gpurun_out/${T}_pytest_fused_build.txt gpurun_out/${T}_pytest_decode_mt_build.txt
 python bench.py > gpurun_out/${T}_bench_bf16.json 2>/dev/null
 python bench.py --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/${T}_bench_bf16_driver_protocol.json 2>/dev/null
 for w in u8 fp16 fp32; do python bench.py --no-cpu-baseline --workload $w > gpurun_out/${T}_bench_$w.json 2>/dev/null; done
