@@ -13,6 +13,17 @@ Workload (BASELINE.json `metric`: "rANS encode+decode GB/s on 256x1 MiB bf16"):
 outputs resident in HBM, temp memory pre-supplied (no allocation in the timed
 region).  One step = one compress pass + one decompress pass over the batch.
 
+THE HEADLINE IS THE CACHE-COLD STEP.  `ms_per_step` / `value` / `roofline` come from
+exactly W warm-up + K timed steps over `--rotate` (4) distinct {input, archive, output}
+buffer sets of different data coded round robin -- 2.9 GB touched per rotation, so
+neither an input nor an archive nor an output line can still be in the 256 MiB
+memory-side cache when its turn comes: every byte the step moves comes from / goes to
+HBM.  A loop that re-codes ONE buffer set (what rounds 1-3 reported, and what the
+reference's own benchmark does) is 15-20 % faster because half its traffic is served
+by that cache; it is printed as a named extra (`ms_per_step_one_buffer_set*`), as are
+the steady-state figures after a pre-roll of >= 400 steps (`*_steady_state`: short
+regions right after an idle fence include the clock ramp).
+
 value = uncompressed input bytes moved per second over all ranks:
         N_gpus * 2 * batch_bytes / step_time   (same definition as the
         reference's benchmark.py:156-157, summed over encode and decode).
@@ -24,9 +35,12 @@ ranks.  After the timed region the ranks all-gather their compressed sizes
 (RCCL) only to report the aggregate ratio.
 
 The JSON line also carries
-  roofline     -- the dominant kernel's algorithmic bytes / its mean duration,
-                  durations measured with HIP events on the launch stream in a
-                  second, instrumented pass of the same K steps;
+  roofline     -- the dominant kernel OF THE HEADLINE LOOP: its algorithmic bytes /
+                  its mean duration, durations measured with HIP events on the
+                  launch stream in a second, instrumented pass of the same loop;
+  roofline_by_direction -- compress = algorithmic bytes / (histogram + encode),
+                  decompress = algorithmic bytes / decode, cold (rotating sets) and
+                  warm (one buffer set), and each direction running alone;
   cpu_baseline -- the CPU oracle (oracle/, kind "port": the reference has no
                   CPU path) timed on this host's cores on a bounded sample.
 Every run ends with a bit-exact round-trip check.
@@ -248,20 +262,42 @@ def measured_traffic(workload, kernel):
 
 
 def cpu_baseline(kind, prob_bits, budget_s=12.0):
-    """Times the CPU oracle (restatement of the reference algorithm; the reference
-    itself has no CPU path) on this host, all cores, on a bounded sample."""
+    """Times the CPU oracle (restatement of the reference algorithm; the reference itself has no CPU path) on this
+    host: persistent threads, one per core and pinned, every buffer allocated and touched before the clock starts
+    (oracle/dietgpu_oracle.c: dgo_bench_roundtrip), two rows of the bench workload per thread.  Round 3's figure
+    (7.9 GB/s on 256 threads = 12 x one thread) timed thread creation, first-touch of fresh output arrays and
+    mmap/munmap of every per-row temporary, not the codec."""
     import oracle as O
     import refgen
 
-    cores = os.cpu_count() or 1
-    rows = max(cores, 16)
+    L = O.lib()
+    L.dgo_bench_roundtrip.restype = C.c_int
+    L.dgo_bench_roundtrip.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_size_t, C.c_uint32, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    try:
+        visible = len(os.sched_getaffinity(0))
+    except AttributeError:
+        visible = os.cpu_count() or 1
+    # What the host really grants: a container may SEE every CPU of the machine and still be held to a CFS quota
+    # (the GPU boxes of this project: 256 visible CPUs, cgroup cpu.max = 16 CPUs' worth -- more runnable threads than
+    # that are throttled, profiles/r04_cpu_scaling_probe.txt).  One thread per granted CPU.
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()
+            quota = None if q == "max" else float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, period = float(f.read()), float(g.read())
+                quota = q / period if q > 0 else None
+        except (OSError, ValueError):
+            pass
+    cores = max(1, min(visible, int(quota))) if quota else visible
+    rows = max(2 * cores, 16)
     n = 512 * 1024
     if kind == "u8":
-        data = refgen.zipf_bytes(rows, 1 << 20)  # rows of the bench workload itself: default_rng(1234 + b)
-        width = data.shape[1]
-        enc = lambda d, th: O.ans_encode_batch(d, prob_bits, threads=th)
-        dec = lambda c, th: O.ans_decode_batch(c, width, prob_bits, threads=th)
-        row_bytes = width
+        data, ft, size = refgen.zipf_bytes(rows, 1 << 20), 0, 1 << 20  # rows of the bench workload: default_rng(1234 + b)
     else:
         ft = {"bf16": O.BFLOAT16, "fp16": O.FLOAT16, "fp32": O.FLOAT32}[kind]
         if kind == "bf16":
@@ -271,41 +307,44 @@ def cpu_baseline(kind, prob_bits, budget_s=12.0):
         else:
             n = n // 2
             data = np.random.default_rng(1234).standard_normal((rows, n), dtype=np.float32).view(np.uint32)
-        enc = lambda d, th: O.float_compress_batch(ft, d, prob_bits, threads=th)
-        dec = lambda c, th: O.float_decompress_batch(ft, c, n, prob_bits, threads=th)
-        row_bytes = n * data.itemsize
+        size = n
+    data = np.ascontiguousarray(data)
+    row_bytes = data.shape[1] * data.itemsize
 
-    def run(d, threads, budget):
-        comp, _ = enc(d, threads)  # warm
-        reps, t_enc, t_dec = 0, 0.0, 0.0
-        t_start = time.perf_counter()
-        while True:
-            t0 = time.perf_counter()
-            comp, _ = enc(d, threads)
-            t1 = time.perf_counter()
-            out = dec(comp, threads)
-            t2 = time.perf_counter()
-            t_enc += t1 - t0
-            t_dec += t2 - t1
-            reps += 1
-            if time.perf_counter() - t_start > budget or reps >= 50:
-                break
-        assert (out == d).all()
-        nbytes = d.shape[0] * row_bytes * reps
-        return 2 * nbytes / (t_enc + t_dec) / 1e9, nbytes / t_enc / 1e9, nbytes / t_dec / 1e9, reps
+    def run(nrows, threads, budget):
+        def call(reps):
+            e, d, bad = C.c_double(0), C.c_double(0), C.c_int(-1)
+            rc = L.dgo_bench_roundtrip(ft, data.ctypes.data, size, row_bytes, nrows, prob_bits, threads, reps, 1,
+                                       C.byref(e), C.byref(d), C.byref(bad))
+            assert rc == 0 and bad.value == 0, "CPU oracle round trip failed"
+            return e.value, d.value
+        e1, d1 = call(1)  # one rep to size the sample
+        reps = int(max(1, min(50, budget / max(e1 + d1, 1e-6))))
+        e, d = call(reps)
+        nbytes = nrows * row_bytes * reps
+        return 2 * nbytes / (e + d) / 1e9, nbytes / e / 1e9, nbytes / d / 1e9, reps
 
-    allc, allc_enc, allc_dec, reps = run(data, cores, budget_s)
-    # SURVEY.md section 8(d) also asks for the single-thread figure: 4 rows, one thread
-    one, one_enc, one_dec, reps1 = run(data[:4], 1, budget_s / 3)
+    import resource
+
+    r0, t0 = resource.getrusage(resource.RUSAGE_SELF), time.perf_counter()
+    allc, allc_enc, allc_dec, reps = run(rows, cores, budget_s)
+    r1, t1 = resource.getrusage(resource.RUSAGE_SELF), time.perf_counter()
+    granted = ((r1.ru_utime + r1.ru_stime) - (r0.ru_utime + r0.ru_stime)) / max(t1 - t0, 1e-9)
+    # SURVEY.md section 8(d) also asks for the single-thread figure: 4 rows on one (pinned) thread
+    one, one_enc, one_dec, reps1 = run(4, 1, budget_s / 3)
     return {
         "value": round(allc, 4),
         "unit": "GB/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{rows} rows of the same workload x {reps} reps, oracle/ C restatement, "
-                  f"{cores} pthreads (one row per task); encode {allc_enc:.3f} GB/s, decode {allc_dec:.3f} GB/s",
+        "sample": f"{rows} rows of the same workload x {reps} reps, oracle/ C restatement, {cores} persistent pinned "
+                  f"pthreads (rows b, b + {cores}, ... per thread), buffers pre-touched; encode {allc_enc:.3f} GB/s, "
+                  f"decode {allc_dec:.3f} GB/s",
+        "speedup_over_one_thread": round(allc / one, 1) if one else None,
+        "host": {"visible_cpus": visible, "cgroup_cpu_quota": quota, "cpu_seconds_per_wall_second": round(granted, 1),
+                 "note": "threads = CPUs the cgroup grants (quota), not the CPUs it can see" if quota and quota < visible else None},
         "single_thread": {"value": round(one, 4), "unit": "GB/s", "cores": 1,
-                          "sample": f"4 rows x {reps1} reps on one thread; encode {one_enc:.3f} GB/s, "
+                          "sample": f"4 rows x {reps1} reps on one pinned thread; encode {one_enc:.3f} GB/s, "
                                     f"decode {one_dec:.3f} GB/s"},
     }
 
@@ -454,11 +493,45 @@ def run_reference_protocol(args, device):
         "rows": rows_out, "round_trip_bit_exact": True}), flush=True)
 
 
+def bind_rank_to_gpu_numa_node(dev_index):
+    """Pins this process to the CPUs of the NUMA node its GPU hangs off (one rank per GPU: host-side launch latency
+    and the pinned parameter blocks then stay node-local).  Best effort; returns what was done, for the JSON line."""
+    info = {"gpu": dev_index, "numa_node": None, "cpus": None}
+    try:
+        props = torch.cuda.get_device_properties(dev_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, props.pci_device_id)
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+            node = int(f.read().strip())
+        info["pci"] = bdf
+        if node < 0:
+            return info  # single-node host (or the platform does not say)
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            cpus = set()
+            for part in f.read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = cpus & os.sched_getaffinity(0)
+        if allowed:
+            os.sched_setaffinity(0, allowed)
+            info["numa_node"], info["cpus"] = node, len(allowed)
+    except (OSError, ValueError, AttributeError) as e:
+        info["note"] = f"not bound: {e}"
+    return info
+
+
+def rccl_version():
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception:  # noqa: BLE001 -- reporting only
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: a timed region of ~0.1 s.  Short regions (20 steps = 5 ms) measure the GPU's clock ramp after
-    # the idle fence as much as the codec: 263 us per step at 20 steps, 229 at 200, 223 at 500 (same build, same box)
+    # defaults: a timed region of ~0.13 s.  Short regions (20 steps = 5 ms) include the GPU's clock ramp after an idle
+    # fence (the *_steady_state extras show the difference)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="bf16", choices=["bf16", "u8", "fp16", "fp32"])
@@ -473,14 +546,16 @@ def main():
                          "(dietgpu_amd.distributed.CompressedAllGatherPlan), effective GB/s per rank")
     ap.add_argument("--chunks", type=int, default=4, help="--collective: pipeline chunks per shard")
     ap.add_argument("--rotate", type=int, default=4,
-                    help="distinct {input, archive, output} buffer sets of the rotating-buffer figure "
-                         "(ms_per_step_rotating); 1 = skip it")
+                    help="distinct {input, archive, output} buffer sets of the headline (cache-cold) loop; "
+                         "1 = re-code one buffer set (the memory-side cache then serves half the traffic)")
     ap.add_argument("--reference-protocol", action="store_true",
                     help="instead of the batched step: the reference's own benchmark protocol (benchmark.py:35-86, "
                          "156-175) -- batch of ONE tensor, 1 M / 16 M / 128 M / 1024 M floats, bf16 and fp16, through "
                          "torch.ops.dietgpu.compress_data / decompress_data with temp_mem, compress and decompress "
                          "GB/s separately; one JSON line with the table")
     ap.add_argument("--ref-sizes", default="1,16,128,1024", help="--reference-protocol: tensor sizes in Mi floats")
+    ap.add_argument("--quick", action="store_true",
+                    help="headline loop, one-buffer-set loop and the per-kernel profiles only (A/B runs: tools/ab.sh)")
     ap.add_argument("--timeline", action="store_true",
                     help="only the timed steps (no per-phase timing / kernel profile): for rocprofv3 timelines")
     args = ap.parse_args()
@@ -521,6 +596,7 @@ def main():
     dev_index = 0 if one_device else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    binding = bind_rank_to_gpu_numa_node(dev_index) if (distributed and not one_device) else None
     import dietgpu_amd as dg
     from dietgpu_amd import distributed as D
 
@@ -547,144 +623,100 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        codec.step()
-    codec.verify()
-    # The driver's literal protocol first: W warm-up steps (just done), then K timed steps -- before the pre-roll below
-    # has settled the clocks.  Reported as `ms_per_step_no_preroll`.
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        codec.step()
-    fence()
-    elapsed_no_preroll = time.perf_counter() - t0
-    if distributed:
-        elapsed_no_preroll = D.max_over_ranks(elapsed_no_preroll, device)
-    # Pre-roll: the GPU's clocks take tens of milliseconds of load to settle (the same build
-    # measures 263 us per step over 20 steps after 3 warm-up steps, 223 us in steady state).  Whatever W and K
-    # are, the timed region starts after at least ~0.1 s of the same work; the K timed steps are untouched.
-    preroll = 0 if args.timeline else max(0, 400 - args.warmup)
-    for _ in range(preroll):
-        codec.step()
+    def over_ranks(seconds):
+        return D.max_over_ranks(seconds, device) if distributed else seconds
 
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        codec.step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    per_rank_ms = [elapsed / args.steps * 1e3]
-    world_seen = 1
-    if distributed:
-        per_rank_ms = [t / args.steps * 1e3 for t in D.gather_scalars(elapsed, device)]
-        elapsed = D.max_over_ranks(elapsed, device)
-        world_seen = dist.get_world_size()
-        assert world_seen == world and len(per_rank_ms) == world
-    codec.verify()
-
-    # separate encode / decode timings (HIP events on the launch stream)
-    def timed(fn, reps):
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(reps):
-            fn()
-        e.record()
-        torch.cuda.synchronize()
-        return s.elapsed_time(e) / reps
-
-    # The rows of one tensor are a stride batch to the library (no parameter block on the device).  The same K steps
-    # as a GENERAL pointer list (elements 0 and 1 swapped): with the parameter cache warm, and with the cache off
-    # (every call uploads its pointer / size arrays: one blit + event records per call).
-    def timed_steps():
-        for _ in range(args.warmup):
-            codec.step()
+    def timed_loop(fn, warmup, steps):
+        """EXACTLY `warmup` untimed + `steps` timed calls of fn(i), barrier + synchronize on both sides, MAX over ranks.
+        Returns seconds for the `steps` calls."""
+        for i in range(warmup):
+            fn(i)
         fence()
-        t = time.perf_counter()
-        for _ in range(args.steps):
-            codec.step()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(warmup + i)
         fence()
-        e = time.perf_counter() - t
-        return D.max_over_ranks(e, device) if distributed else e
+        return time.perf_counter() - t0
 
-    codec.scatter_pointers()
-    elapsed_ptrlist = timed_steps()
-    codec.lib.dgpu_debug_set_param_cache(0)
-    elapsed_uncached = timed_steps()
-    codec.lib.dgpu_debug_set_param_cache(1)
+    K, W = args.steps, args.warmup
+    codec.step()
     codec.verify()
-    codec.scatter_pointers()
-    for _ in range(args.warmup):
-        codec.step()
 
-    if args.timeline:
-        if rank == 0:
-            print(json.dumps({"ms_per_step": round(elapsed / args.steps * 1e3, 4)}))
-        return
-
-    # ROTATING buffers: every step above re-codes the same 256 MiB, and the archive it writes (~180 MB) is smaller
-    # than the 256 MiB memory-side cache, so the decoder may find it there.  Here R distinct {input, archive,
-    # output} sets (different data) are coded round robin -- with the default shape each set touches ~0.7 GB and
-    # four of them 2.8 GB -- so neither an input nor an archive can still be cached when its turn comes again.
-    elapsed_rot, rot_sets, rot_bytes, kernels_rot, rot_extra = None, 0, 0, None, {}
+    # ROTATING buffers: R distinct {input, archive, output} sets (different data) coded round robin.  With the default
+    # shape a set touches ~0.7 GB and four of them 2.9 GB: neither an input nor an archive nor an output can still be
+    # in the 256 MiB memory-side cache when its turn comes again.  This is the headline loop.
+    sets = [codec]
+    rot_sets = 1
     if args.rotate > 1:
         free_b = torch.cuda.mem_get_info(device)[0]
         per_set = codec.in_bytes * 2 + codec.comp.numel()
         rot_sets = int(max(1, min(args.rotate, (free_b - (2 << 30)) // max(per_set, 1) + 1)))
-        sets = [codec]
         for r in range(1, rot_sets):
             d2, _, _, _, _ = make_workload(args.workload, args.batch, 1234 + rank + 1000 * r, device, args.elems)
             c2 = Codec(dg, d2, ft, prob_bits)
             c2.temp = codec.temp  # one temp region: the calls are ordered on one stream
             sets.append(c2)
-        for c2 in sets:
+        for c2 in sets[1:]:
             c2.step()
-        for c2 in sets[1:]:
             c2.verify()
-        rot_bytes = sum(int(c2.sizes.to(torch.int64).sum().item()) + 2 * c2.in_bytes for c2 in sets)
-        for i in range(args.warmup):
-            sets[i % rot_sets].step()
-        fence()
-        t = time.perf_counter()
-        for i in range(args.steps):
-            sets[i % rot_sets].step()
-        fence()
-        elapsed_rot = time.perf_counter() - t
-        if distributed:
-            elapsed_rot = D.max_over_ranks(elapsed_rot, device)
-        for c2 in sets[1:]:
-            c2.verify()
-        # per-kernel durations of the same rotation (HIP events around every launch)
-        prof_rot = kernel_profile(codec, max(args.steps, 100), lambda i: sets[i % rot_sets].step())
-        kernels_rot = {name: round(rec["total_ms"] / max(rec["launches"], 1) * 1e3, 2) for name, rec in prof_rot.items()}
+    cold = rot_sets > 1
+    rot_bytes = sum(int(c2.sizes.to(torch.int64).sum().item()) + 2 * c2.in_bytes for c2 in sets)
+    step_rot = lambda i: sets[i % rot_sets].step()
+    step_one = lambda i: codec.step()
 
-        def rotate(fn):
-            for i in range(args.warmup):
-                fn(sets[i % rot_sets])
-            fence()
-            t_ = time.perf_counter()
-            for i in range(args.steps):
-                fn(sets[i % rot_sets])
-            fence()
-            e_ = time.perf_counter() - t_
-            return (D.max_over_ranks(e_, device) if distributed else e_) / args.steps * 1e3
+    # ---- THE HEADLINE: W warm-up + K timed steps of the cache-cold loop (one buffer set only under --rotate 1)
+    elapsed_local = timed_loop(step_rot, W, K)
+    per_rank_ms = [elapsed_local / K * 1e3]
+    world_seen = 1
+    if distributed:
+        per_rank_ms = [t / K * 1e3 for t in D.gather_scalars(elapsed_local, device)]
+        world_seen = dist.get_world_size()
+        assert world_seen == world and len(per_rank_ms) == world
+    elapsed = over_ranks(elapsed_local)
+    for c2 in sets:
+        c2.verify()
 
-        # The round trip still lets the decoder find the archive its encoder has just written in the memory-side
-        # cache.  The two directions ALONE on rotating buffers -- a sender that only compresses, a receiver that only
-        # decompresses -- share nothing:
-        rot_extra["ms_compress_only_rotating"] = round(rotate(lambda c: c.encode()), 4)
-        rot_extra["ms_decompress_only_rotating"] = round(rotate(lambda c: c.decode()), 4)
+    if args.timeline:
+        if rank == 0:
+            print(json.dumps({"ms_per_step": round(elapsed / K * 1e3, 4), "loop": "rotating" if cold else "one_buffer_set"}))
+        return
+
+    extras = {}
+    ms = lambda seconds, steps=K: round(over_ranks(seconds) / steps * 1e3, 4)
+    # (*_steady_state: the GPU's clocks take tens of milliseconds of load to settle -- the same build measured 263 us per
+    # step over 20 steps after 3 warm-up steps, 223 us in steady state, DESIGN.md section 3 -- so the same loops again
+    # behind a pre-roll of >= 400 steps.  Named extras, not the headline.)
+    preroll = max(0, 400 - W)
+    KS = max(K, 200)
+    # ONE buffer set (rounds 1-3's headline, and the shape of the reference's own benchmark, which re-codes its
+    # tensors): the ~180 MB archive and half of the input / output lines are served by the memory-side cache
+    extras["ms_per_step_one_buffer_set"] = ms(timed_loop(step_one, W, K))
+    if not args.quick:
+        extras["ms_per_step_steady_state"] = ms(timed_loop(step_rot, preroll + W, KS), KS)
+        extras["ms_per_step_one_buffer_set_steady_state"] = ms(timed_loop(step_one, preroll + W, KS), KS)
+        # The rows of one tensor are a stride batch to the library (no parameter block on the device).  The same steps
+        # as a GENERAL pointer list (elements 0 and 1 swapped): with the parameter cache warm, and with the cache off
+        # (every call uploads its pointer / size arrays: one blit + event records per call).
+        codec.scatter_pointers()
+        extras["ms_per_step_one_buffer_set_pointer_list"] = ms(timed_loop(step_one, W, K))
+        codec.lib.dgpu_debug_set_param_cache(0)
+        extras["ms_per_step_one_buffer_set_param_upload_every_call"] = ms(timed_loop(step_one, W, K))
+        codec.lib.dgpu_debug_set_param_cache(1)
+        codec.verify()
+        codec.scatter_pointers()
+    # The two directions ALONE -- a sender that only compresses, a receiver that only decompresses
+    if cold:
+        extras["ms_compress_only"] = ms(timed_loop(lambda i: sets[i % rot_sets].encode(), W, K))
+        extras["ms_decompress_only"] = ms(timed_loop(lambda i: sets[i % rot_sets].decode(), W, K))
+    if cold and not args.quick:
         # ... and the round trip with the histogram pass reading through the cache (dgpu_set_histogram_load_policy(1)):
-        # best for exactly this loop, not the default because it loses wherever only one direction runs
+        # best for exactly this loop, not the default because it loses wherever only one direction runs (DESIGN.md s.3)
         codec.lib.dgpu_set_histogram_load_policy(1)
-        rot_extra["ms_per_step_rotating_cached_histogram_loads"] = round(rotate(lambda c: c.step()), 4)
-        rot_extra["ms_compress_only_rotating_cached_histogram_loads"] = round(rotate(lambda c: c.encode()), 4)
+        extras["ms_per_step_cached_histogram_loads"] = ms(timed_loop(step_rot, W, K))
+        extras["ms_compress_only_cached_histogram_loads"] = ms(timed_loop(lambda i: sets[i % rot_sets].encode(), W, K))
         codec.lib.dgpu_set_histogram_load_policy(-1)
-        del sets
-        for _ in range(args.warmup):
-            codec.step()
-
-    enc_ms = timed(codec.encode, args.steps)
-    dec_ms = timed(codec.decode, args.steps)
+    extras["ms_compress_only_one_buffer_set"] = ms(timed_loop(lambda i: codec.encode(), W, K))
+    extras["ms_decompress_only_one_buffer_set"] = ms(timed_loop(lambda i: codec.decode(), W, K))
 
     sizes = codec.sizes.to(torch.int64)
     comp_total = int(sizes.sum().item())
@@ -695,19 +727,34 @@ def main():
     else:
         ratio = comp_total / codec.in_bytes
 
-    prof = kernel_profile(codec, max(args.steps, 100))  # at least 100 launches per kernel: stable averages for small K
-    codec.verify()
+    # per-kernel durations (HIP events around every launch) of the headline loop and of the one-buffer-set loop;
+    # at least 100 launches per kernel: stable averages for small K
+    P = max(K, 100)
+    for i in range(W):
+        step_rot(i)
+    prof_cold = kernel_profile(codec, P, step_rot)
+    for i in range(W):
+        step_one(i)
+    prof_warm = kernel_profile(codec, P, step_one) if cold else prof_cold
+    for c2 in sets:
+        c2.verify()
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = world * 2 * codec.in_bytes / (elapsed / args.steps) / 1e9
-        kernels = {}
-        for name, rec in prof.items():
-            avg_ms = rec["total_ms"] / max(rec["launches"], 1)
-            ab = algorithmic_bytes(name, codec, comp_total)
-            kernels[name] = {"avg_us": round(avg_ms * 1e3, 2), "launches": rec["launches"]}
-            if ab:
-                kernels[name]["algorithmic_GBps"] = round(ab / (avg_ms * 1e-3) / 1e9, 1)
+        ms_per_step = elapsed / K * 1e3
+        value = world * 2 * codec.in_bytes / (elapsed / K) / 1e9
+
+        def kernel_table(prof):
+            table = {}
+            for name, rec in prof.items():
+                avg_ms = rec["total_ms"] / max(rec["launches"], 1)
+                ab = algorithmic_bytes(name, codec, comp_total)
+                table[name] = {"avg_us": round(avg_ms * 1e3, 2), "launches": rec["launches"]}
+                if ab:
+                    table[name]["algorithmic_GBps"] = round(ab / (avg_ms * 1e-3) / 1e9, 1)
+            return table
+
+        kernels = kernel_table(prof_cold)
+        kernels_warm = kernel_table(prof_warm)
         hot = [k for k in kernels if "algorithmic_GBps" in kernels[k]]
         dom = max(hot, key=lambda k: kernels[k]["avg_us"]) if hot else None
         roofline = None
@@ -718,6 +765,7 @@ def main():
                 "frac": round(ach / HBM_PEAK_GBPS, 4),
                 "avg_us": kernels[dom]["avg_us"],
                 "algorithmic_bytes": algorithmic_bytes(dom, codec, comp_total),
+                "loop": "rotating buffer sets (cache-cold): the headline loop" if cold else "one buffer set (--rotate 1)",
             }
             # the PMC passes are taken on the default shape only, and count only for the build they were taken on
             traffic, note = (measured_traffic(args.workload, dom) if (args.batch == 256 and args.elems == 512 * 1024)
@@ -727,11 +775,31 @@ def main():
                                           "(2*FETCH_SIZE + WRITE_SIZE) KiB per launch; " + note)
         # whole-step figure: algorithmic bytes of encode + decode over the step time
         E = codec.B * codec.elems
-        if ft:
-            wb = 2 if ft in (1, 2) else 4
-            step_alg = 2 * (E * wb + comp_total)  # encode: read words, write archive; decode: the reverse
-        else:
-            step_alg = 2 * (E + comp_total)
+        wb = (2 if ft in (1, 2) else 4) if ft else 1
+        dir_alg = E * wb + comp_total  # one direction: every input byte read once, every output byte written once
+        step_alg = 2 * dir_alg
+
+        def direction(table):
+            """compress = algorithmic bytes of the direction / (histogram + encode), decompress = ... / decode"""
+            hist = next((v["avg_us"] for k, v in table.items() if "histogram" in k), 0.0)
+            enc = sum(v["avg_us"] for k, v in table.items() if k.startswith("k_ans_encode"))
+            dec = sum(v["avg_us"] for k, v in table.items() if k.startswith("k_ans_decode"))
+            frac = lambda us: round(dir_alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if us else None
+            return {"compress": {"kernels_us": round(hist + enc, 2), "histogram_us": hist, "encode_us": enc, "frac": frac(hist + enc)},
+                    "decompress": {"kernels_us": round(dec, 2), "frac": frac(dec)}}
+
+        call_frac = lambda key: (round(dir_alg / (extras[key] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if extras.get(key) else None)
+        by_direction = {
+            "algorithmic_bytes_per_direction": dir_alg, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "cold": direction(kernels) if cold else None,            # kernels of the rotating round trip
+            "warm_one_buffer_set": direction(kernels_warm),
+            # each direction running ALONE (wall clock of the library call, launch gaps included)
+            "cold_alone": {"compress": {"ms": extras.get("ms_compress_only"), "frac": call_frac("ms_compress_only")},
+                           "decompress": {"ms": extras.get("ms_decompress_only"), "frac": call_frac("ms_decompress_only")}} if cold else None,
+            "warm_alone": {"compress": {"ms": extras["ms_compress_only_one_buffer_set"], "frac": call_frac("ms_compress_only_one_buffer_set")},
+                           "decompress": {"ms": extras["ms_decompress_only_one_buffer_set"], "frac": call_frac("ms_decompress_only_one_buffer_set")}},
+            "dominant_kernel_cold": dom,
+        }
         out = {
             "metric": "rans_encode_decode_GBps",
             "baseline_metric": baseline_metric(),
@@ -740,24 +808,21 @@ def main():
             "n_gpus": world,
             "world_size_seen_by_backend": world_seen,
             "dist_backend": args.dist_backend if distributed else None,
+            "rccl_version": rccl_version() if distributed else None,
             "per_rank_ms_per_step": [round(t, 4) for t in per_rank_ms],
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "preroll_steps": preroll,
+            "rank_binding": binding,
+            "steps": K,
+            "warmup": W,
             "ms_per_step": round(ms_per_step, 4),
-            # the same K steps timed straight after the W warm-up steps, BEFORE the pre-roll (the literal protocol)
-            "ms_per_step_no_preroll": round(elapsed_no_preroll / args.steps * 1e3, 4),
-            # K steps over `rotating_sets` distinct {input, archive, output} sets (nothing can stay in the
-            # 256 MiB memory-side cache between two uses); null when --rotate 1
-            "ms_per_step_rotating": round(elapsed_rot / args.steps * 1e3, 4) if elapsed_rot else None,
+            "headline_loop": (f"{rot_sets} rotating {{input, archive, output}} buffer sets, {rot_bytes} bytes touched per "
+                              f"rotation (cache-cold); exactly {W} warm-up + {K} timed steps" if cold else
+                              f"ONE buffer set (--rotate 1): half the traffic is served by the 256 MiB memory-side cache"),
             "rotating_sets": rot_sets,
             "rotating_footprint_bytes": rot_bytes,
-            "kernels_rotating_avg_us": kernels_rot,
-            **rot_extra,
-            "step_frac_of_hbm_peak_rotating": (round(step_alg / (elapsed_rot / args.steps) / 1e9 / HBM_PEAK_GBPS, 4)
-                                               if elapsed_rot else None),
-            "ms_per_step_pointer_list": round(elapsed_ptrlist / args.steps * 1e3, 4),
-            "ms_per_step_param_upload_every_call": round(elapsed_uncached / args.steps * 1e3, 4),
+            "step_algorithmic_GBps": round(step_alg / (elapsed / K) / 1e9, 1),
+            "step_frac_of_hbm_peak": round(step_alg / (elapsed / K) / 1e9 / HBM_PEAK_GBPS, 4),
+            **extras,
+            "steady_state_preroll_steps": preroll,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -768,14 +833,10 @@ def main():
                               "C ABI: dgpu_ans_encode_batch_pointer + dgpu_ans_decode_batch_pointer",
                        "sharding": f"{world} ranks x {args.batch} independent tensors, no data-path collective"},
             "compression_ratio": round(ratio, 4),
-            "encode_GBps": round(codec.in_bytes / (enc_ms * 1e-3) / 1e9, 1),
-            "decode_GBps": round(codec.in_bytes / (dec_ms * 1e-3) / 1e9, 1),
-            "encode_ms": round(enc_ms, 4),
-            "decode_ms": round(dec_ms, 4),
-            "step_algorithmic_GBps": round(step_alg / (elapsed / args.steps) / 1e9, 1),
-            "step_frac_of_hbm_peak": round(step_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS, 4),
             "roofline": roofline,
+            "roofline_by_direction": by_direction,
             "kernels": kernels,
+            "kernels_one_buffer_set": kernels_warm if cold else None,
             "round_trip_bit_exact": True,
         }
         if not args.no_cpu_baseline and world == 1:

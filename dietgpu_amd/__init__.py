@@ -19,6 +19,7 @@ from .ops import (  # noqa: F401
     max_any_compressed_size,
     max_float_compressed_output_size,
     max_float_compressed_size,
+    prefer_torch_ops,
 )
 
 

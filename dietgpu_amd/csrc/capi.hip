@@ -351,8 +351,11 @@ class TempArena {
       overflowUsed_ = true;
       // first overflow allocation of this call: slabs retired by EARLIER calls can go
       // (their kernels precede everything this call enqueues on the stream) -- not while the stream is being
-      // captured: a synchronise would invalidate the capture, they wait for the next plain call
-      if (!s->retired.empty() && !lease_.capturing()) {
+      // captured: a synchronise would invalidate the capture, they wait for the next plain call -- and NEVER once a
+      // call on this stream was captured into a HIP graph: the graph replays with the address of the slab that was
+      // current at capture time, which a later, larger call may have retired.  Those slabs stay until
+      // dgpu_release_graph_state() (the promise of include/dietgpu_amd.h: "neither evicted nor trimmed nor released").
+      if (!s->retired.empty() && !lease_.capturing() && !s->graphPinned) {
         *err = hipStreamSynchronize(lease_.stream());
         if (*err != hipSuccess) return nullptr;
         for (void* p : s->retired) (void)hipFree(p);
@@ -1177,6 +1180,12 @@ int decodeImpl(
   if (errBatch) *errBatch = -1;
   g_mismatches.clear();
   if (B == 0) return DGPU_OK;
+  if (useChecksum && streamIsCapturing(stream)) {
+    // the comparison is host work behind a stream synchronise (as upstream, GpuANSDecode.cuh:557-591): it would
+    // invalidate the capture, and a replay could never repeat it
+    return fail(DGPU_ERR_HIP, "HIP graph capture: checksum verification on decode copies to the host and synchronises the "
+                              "stream; it cannot be captured into a HIP graph (decode with useChecksum = 0 under capture)");
+  }
 
   StreamLease streamLease(stream);
   TempArena arena(temp_dev, tempBytes, streamLease);

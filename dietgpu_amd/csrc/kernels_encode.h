@@ -354,8 +354,19 @@ __device__ __forceinline__ void stageWriteShiftUnder(uint64_t vote, uint32_t add
 // stage of the non-spilling variant holds the proven worst case, encStageWords); with a CALLER-SUPPLIED histogram
 // that does not cover the data it can, and the element is then reported as failed (k_ans_encode): stores beyond
 // the stage land in the neighbouring stages / rings of the same workgroup -- the same, already failed, element --
-// or beyond the workgroup's LDS allocation, where the hardware drops them.
-template <int P, uint32_t FT, bool kFull, bool kSpill>
+// or beyond the workgroup's LDS allocation, where the hardware drops them.  kGuard (k_ans_encode_pair, whose two
+// stages belong to DIFFERENT elements): every kFlushRows rows a half whose word count exceeds what ANY covering table
+// can have produced by then (encGuardLimit) starts over at the stage's first word; with kEncGuardSlackWords of room
+// behind the stage nothing is ever stored outside a half's own stage (three VALU per eight rows).
+// After r rows a lane has emitted at most (r P + 16 + 0.09 r) / 16 words (information conservation: <= P bits per
+// symbol, 16 bits of state head-room, < 0.09 bit of rounding slop per step), a block at most 2 r P + 55.
+__host__ __device__ constexpr uint32_t encGuardLimit(int P, uint32_t row) { return 2u * row * (uint32_t)P + 96u; }
+// ... so between two checks (<= 32 words per row) a guarded stage holds at most encGuardLimit(P, 120) + 256 words
+constexpr uint32_t kEncGuardSlackWords = 192;
+static_assert(encGuardLimit(9, 120) + 256u <= encStageWords(9) + kEncGuardSlackWords &&
+              encGuardLimit(10, 120) + 256u <= encStageWords(10) + kEncGuardSlackWords &&
+              encGuardLimit(11, 120) + 256u <= encStageWords(11) + kEncGuardSlackWords, "");
+template <int P, uint32_t FT, bool kFull, bool kSpill, bool kGuard = false>
 __device__ __forceinline__ uint32_t encodeRows(
     const ChunkSource<FT>& src,
     uint32_t n,                           // symbols in this half's block (0 = idle half)
@@ -376,7 +387,11 @@ __device__ __forceinline__ uint32_t encodeRows(
   bool overrun = false;
 
   // Called every kFlushRows rows: make room for the next kFlushRows rows.
-  auto makeRoom = [&]() {
+  auto makeRoom = [&](uint32_t row) {
+    if (!kSpill && kGuard && outOff > encGuardLimit(P, row)) {
+      outOff = 0;
+      overrun = true;
+    }
     if (!kSpill) return;
     const uint32_t o0 = __builtin_amdgcn_readlane(outOff, 0);
     const uint32_t o1 = __builtin_amdgcn_readlane(outOff, 32);
@@ -464,7 +479,7 @@ __device__ __forceinline__ uint32_t encodeRows(
       for (int r = 0; r < kAhead; ++r) e[r] = fetchEntry(sym[r]);
 #pragma unroll
       for (int r = 0; r < (int)kChunkRows; ++r) {
-        if (r % kFlushRows == 0) makeRoom();
+        if (r % kFlushRows == 0) makeRoom(c * kChunkRows + (uint32_t)r);
         const uint4 cur_e = e[r % kAhead];
         if (r + kAhead < (int)kChunkRows) e[r % kAhead] = fetchEntry(sym[(r + kAhead) % kSymAhead]);
         if (r + kSymAhead < (int)kChunkRows) sym[r % kSymAhead] = symAt(r + kSymAhead);
@@ -478,7 +493,7 @@ __device__ __forceinline__ uint32_t encodeRows(
     // round trip instead of one per row.
 #pragma unroll 1
     for (uint32_t row0 = 0; row0 < maxRows; row0 += kFlushRows) {
-      makeRoom();
+      makeRoom(row0);
       uint32_t word[kFlushRows];
 #pragma unroll
       for (uint32_t j = 0; j < kFlushRows; ++j) {

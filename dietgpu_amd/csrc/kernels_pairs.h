@@ -44,9 +44,13 @@ __device__ __forceinline__ uint32_t halfInclusiveMaxScanDpp(uint32_t v) {
 __device__ __forceinline__ void pairLdsFence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // ---------------------------------------------------------------------------
-// Encoder.  LDS: two 4 KiB tables, two stages, two 512-byte symbol rings.
+// Encoder.  LDS: two 4 KiB tables, two stages, two 512-byte symbol rings.  The two stages belong to different
+// ELEMENTS: the non-spilling ones are guarded (encodeRows, kGuard) and have kEncGuardSlackWords of room behind them.
+__host__ __device__ constexpr uint32_t encPairStageWords(int P, bool spill, uint32_t ft) {
+  return encStageCap(P, spill, ft) + (spill ? 0u : kEncGuardSlackWords);
+}
 __host__ __device__ constexpr uint32_t encPairLdsBytes(int P, bool spill, uint32_t ft) {
-  return 2u * 4096u + 2u * encStageCap(P, spill, ft) * 2u + 2u * 512u;
+  return 2u * 4096u + 2u * encPairStageWords(P, spill, ft) * 2u + 2u * 512u;
 }
 
 // Persistent: workgroup w encodes the pairs w, w + G, ...; a.spill holds [gridDim.x][2][encSpillSlotWords(P)].
@@ -54,7 +58,7 @@ __host__ __device__ constexpr uint32_t encPairLdsBytes(int P, bool spill, uint32
 template <int P, uint32_t FT, bool kSpill>
 __global__ __launch_bounds__(64) void k_ans_encode_pair(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  constexpr uint32_t kCap = encStageCap(P, kSpill, FT);
+  constexpr uint32_t kCap = encPairStageWords(P, kSpill, FT);
   const uint32_t lane = threadIdx.x;
   const bool upper = lane >= 32u;
   const uint32_t hl = lane & 31u;
@@ -122,11 +126,11 @@ __global__ __launch_bounds__(64) void k_ans_encode_pair(EncodeArgs a) {
     uint32_t spilled = 0;
     bool overrun = false;  // see encodeRows: only with a caller-supplied histogram that does not cover the data
     if (bothFull) {
-      words = encodeRows<P, FT, true, kSpill>(src, n, kRowsPerBlock, tableLds, stageLds, ring, hl, upper, spillSlot, spilled,
+      words = encodeRows<P, FT, true, kSpill, !kSpill>(src, n, kRowsPerBlock, tableLds, stageLds, ring, hl, upper, spillSlot, spilled,
                                               state, overrun);
     } else {
       const uint32_t nMax = sLo > sHi ? sLo : sHi;
-      words = encodeRows<P, FT, false, kSpill>(src, n, divUp(nMax, 32u), tableLds, stageLds, nullptr, hl, upper, spillSlot,
+      words = encodeRows<P, FT, false, kSpill, !kSpill>(src, n, divUp(nMax, 32u), tableLds, stageLds, nullptr, hl, upper, spillSlot,
                                                spilled, state, overrun);
     }
     pairLdsFence();  // stage complete

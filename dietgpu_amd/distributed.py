@@ -277,6 +277,12 @@ class CAbiFloatCodec:
         self.ft = _DTYPE_TO_FT[dtype]
         self.P = prob_bits
         self.elems = elems
+        if elems <= 4096:
+            # dgpu_float_compress_stride_capped takes rows of more than one 4096-word block (single-block rows go to
+            # the two-elements-per-wavefront encoder, which does not clamp its copy-out); say so HERE, not at the
+            # first exchange.  Rows that small gain nothing from the codec anyway (~700 bytes of tables per row).
+            raise ValueError(f"compressed collectives need rows of more than 4096 elements (got {elems}): "
+                             "exchange such shards uncompressed, or fold several rows into one")
         self.cap = int(self.L.dgpu_float_max_compressed_size(self.ft, elems))
         self.elem_bytes = torch.empty((), dtype=dtype).element_size()
         self.min_width = (16 + (elems + 15) // 16 * 16 * (3 if self.ft == 3 else 1) + 32 + 512 + 136 * ((elems + 4095) // 4096 + 1) + 15) // 16 * 16
@@ -335,6 +341,7 @@ class CompressedExchangePlan:
         self._max_work = None
         self.out = None
         self.width = None if initial_width is None else self._round_width(initial_width)
+        self._width_agreed = initial_width is None  # widths derived from all-reduced sizes agree by construction
         self.comp_stream = torch.cuda.Stream(self.dev) if self.on_gpu else None
         self.dec_stream = torch.cuda.Stream(self.dev) if self.on_gpu else None
         self.last = {}
@@ -350,6 +357,17 @@ class CompressedExchangePlan:
     def _on(self, s):
         return torch.cuda.stream(s) if s is not None else _NullContext()
 
+    def _agree_on_width(self):
+        """A caller-given initial width must be the SAME on every rank (it is the row stride of the collectives):
+        the first call makes it so (MAX over ranks, one tiny all-reduce, once)."""
+        if self._width_agreed or self.world == 1:
+            self._width_agreed = True
+            return
+        w = torch.tensor([self.width], dtype=torch.int32, device=self.dev)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        self.width = self._round_width(int(w.item()))
+        self._width_agreed = True
+
     def _probe_width(self, rows2d):
         """First call: compress the first chunk once, all ranks agree on max(size) -> width (one host sync)."""
         lo, hi = self.bounds[0]
@@ -359,6 +377,7 @@ class CompressedExchangePlan:
         mx = self.sizes[lo:hi].max().to(torch.int32).reshape(1)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         self.width = self._round_width(int(mx.item()) * (1.0 + self.HEADROOM) + 64)
+        self._width_agreed = True
 
     def _post_compress(self):
         """Right after the last compress call (on the compress stream): the largest archive of all ranks, as an
@@ -370,8 +389,9 @@ class CompressedExchangePlan:
         """The ONE device-to-host read of a step: {largest archive over all ranks, rows that decoded}."""
         torch.sum(self.status.view(-1), dim=0, keepdim=True, dtype=torch.int32, out=self.stat[1:2])
         if statuses_differ_between_ranks and self.world > 1:
-            # in the all-to-all only sender and receiver see a given row's status, and the fall-back is a collective:
-            # every rank must agree on whether it runs
+            # the fall-back is a collective: every rank must agree on whether it runs (in the all-to-all only sender
+            # and receiver see a given row's status; in the all-gather a local decode rejection must not desynchronise
+            # the ranks)
             dist.all_reduce(self.stat[1:2], op=dist.ReduceOp.MIN)
         if self._max_work is not None:
             self._max_work.wait()
@@ -394,6 +414,7 @@ class CompressedExchangePlan:
             self.out = torch.empty((self.world, self.rows, self.elems), dtype=self.dtype, device=self.dev)
         if self.width is None:
             self._probe_width(shard)
+        self._agree_on_width()
         W, world = self.width, self.world
         cur = torch.cuda.current_stream(self.dev) if self.on_gpu else None
         if self.on_gpu:
@@ -421,9 +442,14 @@ class CompressedExchangePlan:
             cur.wait_stream(self.dec_stream)
 
         def fallback():
-            # per ROW: every rank knows every status (the same archives reached everybody); the rows that failed are
-            # gathered again uncompressed, padded to the largest count of any rank
-            bad = (self.status == 0)                                  # [world, rows]
+            # per ROW: the rows that failed are gathered again uncompressed, padded to the largest count of any rank.
+            # Every rank decoded the same archives, so the status matrices SHOULD be equal -- but the fall-back is a
+            # collective whose shapes derive from them, so they are made equal (a row is bad if ANY rank could not
+            # decode it: MIN over ranks of a world x rows byte matrix) rather than assumed to be.
+            agreed = self.status.to(torch.int32)
+            if world > 1:
+                dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+            bad = (agreed == 0)                                       # [world, rows]
             counts = bad.sum(dim=1).tolist()
             width = max(counts)
             mine = bad[dist.get_rank()].nonzero().flatten()
@@ -438,7 +464,8 @@ class CompressedExchangePlan:
                 self.out[r, idx] = got[r, : idx.numel()]
             return counts[dist.get_rank()]
 
-        redo = self._finish("all_gather", fallback, False)  # every rank decoded the same archives
+        # (the count of decoded rows is all-reduced too: every rank must agree on WHETHER the fall-back collective runs)
+        redo = self._finish("all_gather", fallback, True)
         return self.out, redo
 
     # ---- all-to-all
@@ -454,6 +481,7 @@ class CompressedExchangePlan:
         flat = send.view(world * m, self.elems)
         if self.width is None:
             self._probe_width(flat)
+        self._agree_on_width()
         W = self.width
         cur = torch.cuda.current_stream(self.dev) if self.on_gpu else None
         if self.on_gpu:

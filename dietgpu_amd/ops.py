@@ -9,8 +9,16 @@ C ABI of include/dietgpu_amd.h.
 
 Extra keyword `prob_bits` (default 10, as kDefaultPrecision DietGpu.cpp:114)
 exposes the C++ API's ANSCodecConfig.probBits in {9, 10, 11}.
+
+Two routes to the same C ABI.  At the default precision the six codec ops are handed to `torch.ops.dietgpu.*`
+(csrc/torch_ops.cpp: argument checks and pointer marshalling in C++, ~2 us of host time per call) when
+libdietgpu_torch.so is there; the ctypes route below serves `prob_bits` 9 / 11 (the registered ops fix the precision
+at 10, as upstream) and builds without the op library.  256 tensors per call cost ~120 us of Python per op on the
+ctypes route (profiles/r03_api_rate.txt) -- `prefer_torch_ops(False)` forces it (the test-suite runs every parity test
+on both routes).  Either way the work is done by libdietgpu_amd.so: there is no CPU path.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -21,6 +29,32 @@ _DTYPE_TO_FT = {torch.float16: FLOAT16, torch.bfloat16: BFLOAT16, torch.float32:
 _FT_TO_DTYPE = {v: k for k, v in _DTYPE_TO_FT.items()}
 K_DEFAULT_PRECISION = 10
 _U32_MAX = (1 << 32) - 1
+
+
+_PREFER_TORCH_OPS = True
+_TORCH_OPS = None  # None: not tried yet; False: libdietgpu_torch.so is not there
+
+
+def prefer_torch_ops(enable=True):
+    """Route the codec ops through torch.ops.dietgpu.* at prob_bits 10 (default) or force the ctypes route."""
+    global _PREFER_TORCH_OPS
+    _PREFER_TORCH_OPS = bool(enable)
+
+
+def _fast_ops(prob_bits):
+    global _TORCH_OPS
+    if prob_bits != K_DEFAULT_PRECISION or not _PREFER_TORCH_OPS:
+        return None
+    if _TORCH_OPS is None:
+        from .build import TORCH_LIB_PATH
+
+        if os.path.exists(TORCH_LIB_PATH):
+            lib()  # libdietgpu_amd.so first (the op library links against it)
+            torch.ops.load_library(TORCH_LIB_PATH)
+            _TORCH_OPS = torch.ops.dietgpu
+        else:
+            _TORCH_OPS = False
+    return _TORCH_OPS or None
 
 
 def _check(cond, msg="argument check failed"):
@@ -139,6 +173,9 @@ def _validate_out(out_compressed, out_compressed_bytes, rows, cols, dev, device)
 def compress_data(compress_as_float, ts_in, checksum=False, temp_mem=None, out_compressed=None,
                   out_compressed_bytes=None, prob_bits=K_DEFAULT_PRECISION):
     """DietGpu.cpp:149-308 -> (comp [B, maxSize] u8, sizes [B] i32, temp bytes used)."""
+    fast = _fast_ops(prob_bits)
+    if fast is not None:
+        return fast.compress_data(compress_as_float, ts_in, checksum, temp_mem, out_compressed, out_compressed_bytes)
     _check(len(ts_in) > 0)
     dev = ts_in[0].get_device()
     rows, cols = (max_float_compressed_output_size(ts_in) if compress_as_float
@@ -172,6 +209,10 @@ def compress_data_split_size(compress_as_float, t_in, t_in_split_sizes, checksum
                              temp_mem=None, out_compressed=None, out_compressed_bytes=None,
                              prob_bits=K_DEFAULT_PRECISION):
     """DietGpu.cpp:310-452 -> (list of compressed row views, sizes, temp bytes used)."""
+    fast = _fast_ops(prob_bits)
+    if fast is not None:
+        return fast.compress_data_split_size(compress_as_float, t_in, t_in_split_sizes, checksum, temp_mem, out_compressed,
+                                             out_compressed_bytes)
     dev = t_in.get_device()
     _check(t_in.is_cuda and t_in.is_contiguous())
     ft = _float_type(t_in) if compress_as_float else 0
@@ -210,6 +251,9 @@ def compress_data_split_size(compress_as_float, t_in, t_in_split_sizes, checksum
 def compress_data_simple(compress_as_float, ts_in, checksum=False, temp_mem=67108864,
                          prob_bits=K_DEFAULT_PRECISION):
     """DietGpu.cpp:454-522 -> list of exactly-sized compressed tensors."""
+    fast = _fast_ops(prob_bits)
+    if fast is not None:
+        return fast.compress_data_simple(compress_as_float, ts_in, checksum, temp_mem)
     _check(len(ts_in) > 0)
     scratch = None
     if temp_mem is not None and temp_mem > 0:
@@ -242,6 +286,9 @@ def _raise_checksum(rc, is_float):
 def decompress_data(compress_as_float, ts_in, ts_out, checksum=False, temp_mem=None,
                     out_status=None, out_decompressed_words=None, prob_bits=K_DEFAULT_PRECISION):
     """DietGpu.cpp:530-677 -> temp bytes used."""
+    fast = _fast_ops(prob_bits)
+    if fast is not None:
+        return fast.decompress_data(compress_as_float, ts_in, ts_out, checksum, temp_mem, out_status, out_decompressed_words)
     _check(len(ts_in) > 0)
     _check(len(ts_in) == len(ts_out))
     dev = ts_in[0].get_device()
@@ -279,6 +326,10 @@ def decompress_data_split_size(compress_as_float, ts_in, t_out, t_out_split_size
                                temp_mem=None, out_status=None, out_decompressed_words=None,
                                prob_bits=K_DEFAULT_PRECISION):
     """DietGpu.cpp:679-816 -> temp bytes used."""
+    fast = _fast_ops(prob_bits)
+    if fast is not None:
+        return fast.decompress_data_split_size(compress_as_float, ts_in, t_out, t_out_split_sizes, checksum, temp_mem, out_status,
+                                               out_decompressed_words)
     _check(len(ts_in) > 0)
     dev = ts_in[0].get_device()
     ss = t_out_split_sizes
@@ -314,6 +365,9 @@ def decompress_data_split_size(compress_as_float, ts_in, t_out, t_out_split_size
 def decompress_data_simple(compress_as_float, ts_in, checksum=False, temp_mem=67108864,
                            prob_bits=K_DEFAULT_PRECISION):
     """DietGpu.cpp:818-911 -> list of decompressed tensors (sizes/dtypes read from the headers)."""
+    fast = _fast_ops(prob_bits)
+    if fast is not None:
+        return fast.decompress_data_simple(compress_as_float, ts_in, checksum, temp_mem)
     _check(len(ts_in) > 0)
     dev = ts_in[0].get_device()
     device = ts_in[0].device

@@ -3,9 +3,11 @@
 TEST INFRASTRUCTURE ONLY.  May be imported by tests/, __graft_entry__.smoke()
 and bench.py's cpu_baseline leg -- never by the product package dietgpu_amd/.
 
-Parity status: "parity unpinned" for compressed bytes (the reference is
-CUDA-only, cannot be built here and ships no golden bitstreams); pinned by the
-reference's known-answer tests, see oracle/dietgpu_oracle.h.
+Parity status: PINNED.  The reference ships no golden bitstreams and its build
+system cannot run here, but its own sources compile with g++ against a CPU
+emulation of the CUDA execution model (oracle/_ref, oracle/ref.py); tests/
+test_reference_pin.py compares this restatement with it byte for byte, and the
+golden fixtures under tests/golden/ are its outputs.
 """
 import ctypes as C
 import os

@@ -10,9 +10,13 @@
  * (GpuANSStatistics.cuh:215) must be a correctly rounded fp32 divide followed
  * by a correctly rounded fp32 multiply, then truncation.
  */
+#define _GNU_SOURCE /* pthread barriers / affinity, mallopt (the bench leg at the end of this file) */
 #include "dietgpu_oracle.h"
 
+#include <malloc.h>
 #include <pthread.h>
+#include <sched.h>
+#include <time.h>
 #include <stdlib.h>
 #include <limits.h>
 #include <string.h>
@@ -615,4 +619,118 @@ void dgo_float_decompress_batch(
   j.probBits = probBits; j.out = (uint8_t*)out; j.outStride = outStride;
   j.cap = outCapacityFloats;
   run_jobs(j, threads);
+}
+
+
+/* ------------------------------------------------- timed round trip (bench.py's cpu_baseline leg)
+ * What the one-call-per-phase helpers above cost on a many-core host is mostly NOT the codec: every call creates and
+ * joins its threads, the caller allocates (and first-touches) fresh output arrays, and the per-element temporaries
+ * (the 512 KiB exponent plane of a float row) are above glibc's mmap threshold, so 256 threads queue on the process's
+ * address-space lock.  Here: persistent threads (one per core, pinned when asked), every buffer allocated and touched
+ * before the clock starts, malloc kept off mmap, phases separated by barriers and timed inside.  Row b belongs to
+ * thread b mod T.  Returns 0, or -1 on allocation / thread failure; *mismatches = rows that did not round-trip. */
+typedef struct {
+  uint32_t ft; const uint8_t* in; size_t inStride; uint32_t size; uint32_t batch; int probBits;
+  uint8_t* comp; size_t compStride; uint8_t* out; size_t rowBytes;
+  int tid, nthreads, reps, pin;
+  pthread_barrier_t* bar; double* encSeconds; double* decSeconds; int* bad;
+} bench_t;
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void* bench_worker(void* p) {
+  bench_t* j = (bench_t*)p;
+  if (j->pin) {
+    /* the tid-th CPU of the set this process may run on */
+    cpu_set_t allowed, one;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0) {
+      int want = j->tid % CPU_COUNT(&allowed), seen = 0;
+      for (int c = 0; c < CPU_SETSIZE; ++c) {
+        if (!CPU_ISSET(c, &allowed)) continue;
+        if (seen++ == want) {
+          CPU_ZERO(&one);
+          CPU_SET(c, &one);
+          (void)pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
+          break;
+        }
+      }
+    }
+  }
+  double enc = 0.0, dec = 0.0;
+  for (int rep = -1; rep < j->reps; ++rep) { /* rep -1: untimed (first touch of every page, warm caches) */
+    pthread_barrier_wait(j->bar);
+    const double t0 = now_s();
+    for (uint32_t b = (uint32_t)j->tid; b < j->batch; b += (uint32_t)j->nthreads) {
+      const uint8_t* in = j->in + (size_t)b * j->inStride;
+      uint8_t* c = j->comp + (size_t)b * j->compStride;
+      if (j->ft) (void)dgo_float_compress(j->ft, in, j->size, j->probBits, 0, c);
+      else (void)dgo_ans_encode(in, j->size, j->probBits, 0, NULL, c);
+    }
+    pthread_barrier_wait(j->bar);
+    const double t1 = now_s();
+    for (uint32_t b = (uint32_t)j->tid; b < j->batch; b += (uint32_t)j->nthreads) {
+      const uint8_t* c = j->comp + (size_t)b * j->compStride;
+      uint8_t* o = j->out + (size_t)b * j->rowBytes;
+      uint32_t sz = 0;
+      if (j->ft) (void)dgo_float_decompress(j->ft, c, j->probBits, o, j->size, &sz);
+      else (void)dgo_ans_decode(c, j->probBits, o, j->size, &sz);
+    }
+    pthread_barrier_wait(j->bar);
+    const double t2 = now_s();
+    if (rep >= 0) { enc += t1 - t0; dec += t2 - t1; }
+  }
+  if (j->tid == 0) { *j->encSeconds = enc; *j->decSeconds = dec; }
+  int bad = 0;
+  for (uint32_t b = (uint32_t)j->tid; b < j->batch; b += (uint32_t)j->nthreads) {
+    if (memcmp(j->in + (size_t)b * j->inStride, j->out + (size_t)b * j->rowBytes, j->rowBytes) != 0) ++bad;
+  }
+  __atomic_fetch_add(j->bad, bad, __ATOMIC_RELAXED);
+  return NULL;
+}
+
+int dgo_bench_roundtrip(
+    uint32_t ft, const void* in, uint32_t size, size_t inStride, uint32_t batch, int probBits, int threads, int reps,
+    int pin, double* encSeconds, double* decSeconds, int* mismatches) {
+  if (threads < 1) threads = 1;
+  /* per-element temporaries (up to `size` bytes) from the arena heaps, not from mmap / munmap per call */
+  mallopt(M_MMAP_THRESHOLD, 1 << 30);
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
+  const size_t wordBytes = ft == 3 ? 4 : (ft ? 2 : 1);
+  const size_t rowBytes = (size_t)size * wordBytes;
+  const size_t compStride = ft ? dgo_float_max_compressed_size(ft, size) : dgo_ans_max_compressed_size(size);
+  uint8_t* comp = (uint8_t*)malloc(compStride * batch + 64);
+  uint8_t* out = (uint8_t*)malloc(rowBytes * batch + 64);
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
+  bench_t* jobs = (bench_t*)malloc(sizeof(bench_t) * (size_t)threads);
+  pthread_barrier_t bar;
+  int bad = 0, rc = 0;
+  if (!comp || !out || !th || !jobs || pthread_barrier_init(&bar, NULL, (unsigned)threads) != 0) {
+    free(comp); free(out); free(th); free(jobs);
+    return -1;
+  }
+  int started = 0;
+  for (int t = 0; t < threads; ++t) {
+    bench_t j;
+    memset(&j, 0, sizeof(j));
+    j.ft = ft; j.in = (const uint8_t*)in; j.inStride = inStride; j.size = size; j.batch = batch; j.probBits = probBits;
+    j.comp = comp; j.compStride = compStride; j.out = out; j.rowBytes = rowBytes;
+    j.tid = t; j.nthreads = threads; j.reps = reps; j.pin = pin;
+    j.bar = &bar; j.encSeconds = encSeconds; j.decSeconds = decSeconds; j.bad = &bad;
+    jobs[t] = j;
+    if (pthread_create(&th[t], NULL, bench_worker, &jobs[t]) != 0) { rc = -1; break; }
+    ++started;
+  }
+  if (rc != 0) {
+    /* cannot release threads parked on a barrier that will never fill: leave them (test infrastructure) */
+    return -1;
+  }
+  for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+  pthread_barrier_destroy(&bar);
+  if (mismatches) *mismatches = bad;
+  free(comp); free(out); free(th); free(jobs);
+  return 0;
 }

@@ -82,6 +82,18 @@ def lib():
         L.dgref_float_compress_split_size.argtypes = [u32, i32, i32, i32, u32, vp, vp, vp, u32, vp]
         L.dgref_float_decompress_split_size.restype = i32
         L.dgref_float_decompress_split_size.argtypes = [u32, i32, i32, i32, u32, vp, vp, vp, vp, vp]
+        L.dgref_ans_encode_batch_hist.restype = None
+        L.dgref_ans_encode_batch_hist.argtypes = [i32, i32, u32, vp, vp, vp, vp, vp]
+        L.dgref_ans_encode_batch_stride_hist.restype = None
+        L.dgref_ans_encode_batch_stride_hist.argtypes = [i32, i32, u32, vp, u32, u32, vp, vp, u32, vp]
+        L.dgref_ans_encode_batch_split_size_hist.restype = None
+        L.dgref_ans_encode_batch_split_size_hist.argtypes = [i32, i32, u32, vp, vp, vp, vp, u32, vp]
+        for name in ("dgref_ans_get_compressed_info", "dgref_ans_get_compressed_info_device"):
+            getattr(L, name).restype = None
+            getattr(L, name).argtypes = [u32, vp, vp, vp]
+        for name in ("dgref_float_get_compressed_info", "dgref_float_get_compressed_info_device"):
+            getattr(L, name).restype = None
+            getattr(L, name).argtypes = [u32, vp, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -310,3 +322,85 @@ def float_decompress_split_size(ft, archives, sizes_out, prob_bits=10, use_check
         outs.append(out[pos * wb : (pos + n) * wb].view(_WORD[ft]).copy())
         pos += n
     return outs, ok, osz, rc
+
+
+# ---- caller-supplied histograms: `histogram_dev` of ansEncodeBatch{Pointer,Stride,SplitSize} (GpuANSCodec.h:65-164) ----
+def _hist_arg(counts, b):
+    counts = np.ascontiguousarray(counts, np.uint32).reshape(b, 256)
+    return counts, counts.ctypes.data_as(C.c_void_p)
+
+
+def ans_encode_batch_hist(rows, counts, prob_bits=10, use_checksum=False, provider="pointer"):
+    """rows (equal lengths for provider="stride") + [B][256] counts -> list of archives.  The reference normalises the
+    counts it is GIVEN against each row's size and never looks at the data's own statistics (GpuANSEncode.cuh:692-700)."""
+    L = lib()
+    b = len(rows)
+    keep, hp = _hist_arg(counts, b)
+    sizes_in = [len(r) for r in rows]
+    out_sizes = np.zeros(b, np.uint32)
+    if provider == "pointer":
+        ins = []
+        for r in rows:
+            a = _aligned(max(len(r), 4))
+            a[: len(r)] = r
+            ins.append(a)
+        sizes = (C.c_uint32 * b)(*sizes_in)
+        outs = [_aligned(int(L.dgref_ans_max_compressed_size(len(r)))) for r in rows]
+        L.dgref_ans_encode_batch_hist(prob_bits, int(use_checksum), b, _ptrs(ins), sizes, hp, _ptrs(outs),
+                                      out_sizes.ctypes.data_as(C.c_void_p))
+        return [o[:n].copy() for o, n in zip(outs, out_sizes)]
+    out_stride = int(L.dgref_ans_max_compressed_size(max(sizes_in)))
+    out = _aligned(b * out_stride)
+    if provider == "stride":
+        n = sizes_in[0]
+        assert all(x == n for x in sizes_in)
+        buf = _aligned(b * n + 16)
+        for i, r in enumerate(rows):
+            buf[i * n : (i + 1) * n] = r
+        L.dgref_ans_encode_batch_stride_hist(prob_bits, int(use_checksum), b, C.c_void_p(buf.ctypes.data), n, n, hp,
+                                             C.c_void_p(out.ctypes.data), out_stride, out_sizes.ctypes.data_as(C.c_void_p))
+    elif provider == "split_size":
+        buf = _aligned(sum(sizes_in) + 16)
+        pos = 0
+        for r in rows:
+            buf[pos : pos + len(r)] = r
+            pos += len(r)
+        split = (C.c_uint32 * b)(*sizes_in)
+        L.dgref_ans_encode_batch_split_size_hist(prob_bits, int(use_checksum), b, C.c_void_p(buf.ctypes.data), split, hp,
+                                                 C.c_void_p(out.ctypes.data), out_stride, out_sizes.ctypes.data_as(C.c_void_p))
+    else:
+        raise ValueError(provider)
+    del keep
+    return [out[i * out_stride : i * out_stride + out_sizes[i]].copy() for i in range(b)]
+
+
+# ---- header info: ansGetCompressedInfo(Device) / floatGetCompressedInfo(Device) ---------------------------------
+def _hold(archives):
+    ins = []
+    for a in archives:
+        b = _aligned(len(a))
+        b[:] = a
+        ins.append(b)
+    return ins
+
+
+def ans_get_compressed_info(archives, want_checksum=False, device=False):
+    """-> (sizes, checksums or None).  device=True goes through the *Device entry point (pointer array "on the device")."""
+    ins = _hold(archives)
+    sizes = np.zeros(len(archives), np.uint32)
+    ck = np.zeros(len(archives), np.uint32) if want_checksum else None
+    fn = lib().dgref_ans_get_compressed_info_device if device else lib().dgref_ans_get_compressed_info
+    fn(len(archives), _ptrs(ins), sizes.ctypes.data_as(C.c_void_p), ck.ctypes.data_as(C.c_void_p) if want_checksum else None)
+    return sizes, ck
+
+
+def float_get_compressed_info(archives, want_checksum=False, device=False):
+    """-> (sizes in float words, float types, checksums or None)."""
+    ins = _hold(archives)
+    sizes = np.zeros(len(archives), np.uint32)
+    types = np.zeros(len(archives), np.uint32)
+    ck = np.zeros(len(archives), np.uint32) if want_checksum else None
+    fn = lib().dgref_float_get_compressed_info_device if device else lib().dgref_float_get_compressed_info
+    fn(len(archives), _ptrs(ins), sizes.ctypes.data_as(C.c_void_p), types.ctypes.data_as(C.c_void_p),
+       ck.ctypes.data_as(C.c_void_p) if want_checksum else None)
+    return sizes, types, ck

@@ -181,4 +181,49 @@ int dgref_float_decompress_split_size(uint32_t ft, int probBits, int useChecksum
   return 0;
 }
 
+// ---- caller-supplied histograms (GpuANSCodec.h:65-164: `histogram_dev`, [num][256] u32, nullable; the encoder then
+// skips ansHistogramBatch and normalises what it was given, GpuANSEncode.cuh:692-700) -------------------------------
+void dgref_ans_encode_batch_hist(int probBits, int useChecksum, uint32_t num, const void* const* in, const uint32_t* inSize,
+                                 const uint32_t* histogram, void* const* out, uint32_t* outSize) {
+  ANSCodecConfig cfg(probBits, useChecksum != 0);
+  StackDeviceMemory res(0, stackBytes(num, inSize, 1));
+  ansEncodeBatchPointer(res, cfg, num, (const void**)in, inSize, histogram, (void**)out, outSize, nullptr);
+}
+void dgref_ans_encode_batch_stride_hist(int probBits, int useChecksum, uint32_t num, const void* in, uint32_t inSize,
+                                        uint32_t inStride, const uint32_t* histogram, void* out, uint32_t outStride,
+                                        uint32_t* outSize) {
+  ANSCodecConfig cfg(probBits, useChecksum != 0);
+  std::vector<uint32_t> sizes(num, inSize);
+  StackDeviceMemory res(0, stackBytes(num, sizes.data(), 1));
+  ansEncodeBatchStride(res, cfg, num, in, inSize, inStride, histogram, out, outStride, outSize, nullptr);
+}
+void dgref_ans_encode_batch_split_size_hist(int probBits, int useChecksum, uint32_t num, const void* in,
+                                            const uint32_t* splitSizes, const uint32_t* histogram, void* out,
+                                            uint32_t outStride, uint32_t* outSize) {
+  ANSCodecConfig cfg(probBits, useChecksum != 0);
+  StackDeviceMemory res(0, stackBytes(num, splitSizes, 1));
+  ansEncodeBatchSplitSize(res, cfg, num, in, splitSizes, histogram, out, outStride, outSize, nullptr);
+}
+
+// ---- header info (GpuANSCodec.h:309-341, GpuFloatCodec.h:252-292); any output may be null ---------------------------
+// (the reference ASSERTS getUseChecksum() when a checksum is asked for: only ask on archives made with checksums)
+void dgref_ans_get_compressed_info(uint32_t num, const void* const* in, uint32_t* outSizes, uint32_t* outChecksum) {
+  StackDeviceMemory res(0, (size_t)1 << 20);
+  ansGetCompressedInfo(res, (const void**)in, num, outSizes, outChecksum, nullptr);
+}
+void dgref_ans_get_compressed_info_device(uint32_t num, const void* const* in_dev, uint32_t* outSizes, uint32_t* outChecksum) {
+  StackDeviceMemory res(0, (size_t)1 << 20);
+  ansGetCompressedInfoDevice(res, (const void**)in_dev, num, outSizes, outChecksum, nullptr);
+}
+void dgref_float_get_compressed_info(uint32_t num, const void* const* in, uint32_t* outSizes, uint32_t* outTypes,
+                                     uint32_t* outChecksum) {
+  StackDeviceMemory res(0, (size_t)1 << 20);
+  floatGetCompressedInfo(res, (const void**)in, num, outSizes, outTypes, outChecksum, nullptr);
+}
+void dgref_float_get_compressed_info_device(uint32_t num, const void* const* in_dev, uint32_t* outSizes, uint32_t* outTypes,
+                                            uint32_t* outChecksum) {
+  StackDeviceMemory res(0, (size_t)1 << 20);
+  floatGetCompressedInfoDevice(res, (const void**)in_dev, num, outSizes, outTypes, outChecksum, nullptr);
+}
+
 }  // extern "C"

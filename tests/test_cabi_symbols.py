@@ -67,3 +67,47 @@ def test_ops_argument_validation_without_gpu():
         dg.compress_data(False, [torch.zeros(16, dtype=torch.uint8)])
     assert dg.max_any_compressed_size(1 << 20) == 1868320
     assert dg.max_float_compressed_size(torch.empty(0, dtype=torch.bfloat16), 524288) == 1737264
+
+
+def _read(*parts):
+    return open(os.path.join(ROOT, *parts)).read()
+
+
+def test_every_c_abi_function_has_a_test_caller():
+    """Every dgpu_* function of include/dietgpu_amd.h is CALLED by a test: directly (tests/*.py, tests/cpp/*.cpp) or
+    through one of the two tensor surfaces the GPU suite runs on (dietgpu_amd/ops.py, csrc/torch_ops.cpp) /
+    dietgpu_amd/distributed.py.  A function that only the C++ mirror headers mention does not count (the mirror's own
+    functions are checked below)."""
+    direct = "".join(_read("tests", f) for f in os.listdir(os.path.join(ROOT, "tests")) if f.endswith(".py") and f != "test_cabi_symbols.py")
+    direct += "".join(_read("tests", "cpp", f) for f in os.listdir(os.path.join(ROOT, "tests", "cpp")))
+    surfaces = _read("dietgpu_amd", "ops.py") + _read("dietgpu_amd", "csrc", "torch_ops.cpp") + _read("dietgpu_amd", "distributed.py")
+    called = lambda name, text: re.search(r"\b%s\s*\(" % re.escape(name), text) is not None
+    missing, only_indirect = [], []
+    for n in declared_functions():
+        if called(n, direct):
+            continue
+        (only_indirect if called(n, surfaces) else missing).append(n)
+    assert not missing, f"C-ABI functions no test reaches: {missing}"
+    # The five the round-3 review found with no caller at all now have DIRECT ones (tests/test_gpu_cabi.py):
+    for n in ("dgpu_ans_decode_batch_split_size", "dgpu_float_decompress_split_size", "dgpu_ans_get_compressed_info_device",
+              "dgpu_float_get_compressed_info_device", "dgpu_ans_decode_batch_pointer", "dgpu_float_decompress"):
+        assert called(n, direct), n
+    # ... and `histogram_dev` is passed as a real pointer to all three encode entry points
+    cabi = _read("tests", "test_gpu_cabi.py")
+    for n in ("dgpu_ans_encode_batch_pointer", "dgpu_ans_encode_batch_stride", "dgpu_ans_encode_batch_split_size"):
+        assert re.search(r"%s\([^;]*hist\.data_ptr" % n, cabi, flags=re.S), n
+
+
+def test_every_function_of_the_cpp_mirror_is_called_by_the_cpp_test():
+    """include/dietgpu_amd/Gpu{ANS,Float}Codec.h re-create the dietgpu:: signatures; tests/cpp/api_roundtrip.cpp calls
+    every one of them (stride, pointer, split-size, info, device-info; encode with a caller's histogram)."""
+    cpp = _read("tests", "cpp", "api_roundtrip.cpp")
+    names = []
+    for hdr in ("GpuANSCodec.h", "GpuFloatCodec.h"):
+        text = _read("include", "dietgpu_amd", hdr)
+        text = text.split("}  // namespace detail")[-1]  # the public functions follow the detail namespace
+        names += re.findall(r"^inline\s+[\w:]+\s+(\w+)\s*\(", text, flags=re.M)
+    assert len(names) >= 14, names
+    missing = [n for n in names if not re.search(r"\b%s\s*\(" % n, cpp)]
+    assert not missing, missing
+    assert re.search(r"ansEncodeBatch\w+\([^;]*hist", cpp), "no C++ call passes histogram_dev"

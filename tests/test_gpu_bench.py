@@ -1,0 +1,82 @@
+"""bench.py as the driver runs it: the JSON line's contract, the N > 1 launch path on one device, and the N = 1 path
+under torch.distributed.run against the bare one (the 8-GPU run must not fail for a trivial reason)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+SMALL = ["--steps", "6", "--warmup", "2", "--batch", "64", "--no-cpu-baseline", "--rotate", "2"]
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def _line(p):
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly ONE JSON line"
+    return json.loads(lines[0])
+
+
+def _check_contract(d, n_gpus):
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "roofline_by_direction"):
+        assert key in d, key
+    assert d["n_gpus"] == n_gpus and d["world_size_seen_by_backend"] == n_gpus and len(d["per_rank_ms_per_step"]) == n_gpus
+    assert d["round_trip_bit_exact"] and d["scaling"] == "weak" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    # value = whole-job uncompressed bytes through encode + decode / the MAX-over-ranks step time
+    assert abs(d["value"] - n_gpus * 2 * d["config"]["per_gpu_batch_bytes"] / (d["ms_per_step"] * 1e-3) / 1e9) < 0.01 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["algorithmic_bytes"] / (r["avg_us"] * 1e-6) / 1e9) < 0.02 * r["achieved"]
+    # the headline is the cache-cold loop; the one-buffer-set figure is a named extra
+    assert "rotating" in d["headline_loop"] and d["rotating_sets"] >= 2 and "ms_per_step_one_buffer_set" in d
+    bd = d["roofline_by_direction"]
+    assert bd["cold"]["compress"]["frac"] > 0 and bd["cold"]["decompress"]["frac"] > 0 and bd["warm_one_buffer_set"]["compress"]["frac"] > 0
+
+
+def test_default_style_line_and_cpu_baseline():
+    p = subprocess.run([sys.executable, BENCH, "--steps", "6", "--warmup", "2", "--batch", "64", "--rotate", "2"],
+                       capture_output=True, text=True, timeout=900, env=_clean_env())
+    d = _line(p)
+    _check_contract(d, 1)
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "GB/s" and c["cores"] >= 1 and c["value"] > 0 and c["single_thread"]["value"] > 0
+    # persistent pinned threads, one per CPU the host GRANTS (cgroup quota): the figure scales with them
+    assert c["cores"] <= c["host"]["visible_cpus"] and c["value"] > 0.5 * c["cores"] * c["single_thread"]["value"], c
+
+
+def test_one_rank_under_torchrun_equals_the_bare_path():
+    bare = _line(subprocess.run([sys.executable, BENCH, "--gpus", "1"] + SMALL, capture_output=True, text=True, timeout=600,
+                                env=_clean_env()))
+    run = _line(subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+                                "127.0.0.1", "--master-port", "29571", BENCH, "--gpus", "1"] + SMALL,
+                               capture_output=True, text=True, timeout=600, env=_clean_env()))
+    _check_contract(bare, 1)
+    _check_contract(run, 1)
+    assert set(bare) == set(run) and bare["config"] == run["config"] and bare["metric"] == run["metric"]
+    assert 0.7 < bare["ms_per_step"] / run["ms_per_step"] < 1.4, (bare["ms_per_step"], run["ms_per_step"])
+
+
+def test_two_ranks_on_one_device():
+    # python bench.py --gpus 2 starts its own two ranks (gloo here, both on GPU 0: the box has one GPU)
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dist-backend", "gloo"] + SMALL, capture_output=True, text=True,
+                       timeout=900, env=_clean_env(DGPU_BENCH_ONE_DEVICE="1"))
+    d = _line(p)
+    _check_contract(d, 2)
+    assert d["dist_backend"] == "gloo"
+
+
+def test_wrong_world_size_is_refused():
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + SMALL, capture_output=True, text=True, timeout=300,
+                       env=_clean_env(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stdout + p.stderr)

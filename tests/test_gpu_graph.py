@@ -137,3 +137,92 @@ def test_graph_survives_parameter_cache_churn_and_reports_unwarmed_capture():
         assert torch.equal(x.view(torch.int16), o.view(torch.int16))
     del graph
     assert L.dgpu_release_graph_state() >= 1  # the pinned block(s) become evictable again
+
+
+def test_graph_survives_growth_of_the_overflow_slab():
+    """a call captured with temp_mem=None bakes the address of the stream's library-owned overflow
+    slab into the graph.  A later, LARGER call on the same stream makes the slab grow: the old slab is retired -- and
+    must not be freed by the call after that, because the graph still replays into it."""
+    import dietgpu_amd
+    from dietgpu_amd import ops
+
+    L = dietgpu_amd.lib()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    g0 = torch.Generator(device="cpu").manual_seed(23)
+    B, n = 4, 60_000
+    xs = [torch.randn(n + 8 * i, generator=g0).to(torch.bfloat16).to(dev) for i in range(B)]
+    rows, cols = ops.max_float_compressed_output_size(xs)
+    comp = torch.empty((rows, cols), dtype=torch.uint8, device=dev)
+    sizes = torch.zeros((rows,), dtype=torch.int32, device=dev)
+    outs = [torch.empty_like(x) for x in xs]
+    status = torch.zeros((B,), dtype=torch.uint8, device=dev)
+
+    def roundtrip():
+        ops.compress_data(True, xs, False, None, comp, sizes)
+        ops.decompress_data(True, [comp[i] for i in range(B)], outs, False, None, status, None)
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        roundtrip()  # warm: parameter blocks resident, the stream's slab exists (small: this batch needs a few MiB)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        roundtrip()
+    torch.cuda.synchronize()
+    # a much larger batch on the same stream, twice, without temp memory: the first call grows the slab (retiring
+    # the one the graph knows), the second is the call that used to free retired slabs
+    big = [torch.randn(3_000_000, generator=g0).to(torch.bfloat16).to(dev) for _ in range(24)]
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            c2, s2, _ = ops.compress_data(True, big, False, None)
+            torch.cuda.synchronize()
+        # memory freed under the graph would be handed out again here
+        scratch = [torch.full((8 << 20,), 0xAB, dtype=torch.uint8, device=dev) for _ in range(24)]
+    torch.cuda.synchronize()
+    for trial in range(2):
+        for x in xs:
+            x.copy_(torch.randn(x.numel(), generator=g0).to(torch.bfloat16))
+        for o in outs:
+            o.zero_()
+        status.zero_()
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert bool(status.all())
+        for x, o in zip(xs, outs):
+            assert torch.equal(x.view(torch.int16), o.view(torch.int16)), trial
+        assert all(bool((t == 0xAB).all()) for t in scratch)  # ... and the replay wrote nowhere else
+    del graph, scratch
+    assert L.dgpu_release_graph_state() >= 1
+
+
+def test_checksum_verification_cannot_be_captured():
+    """decode with checksum verification is host work behind a synchronise; under stream capture the call
+    is refused with a message instead of invalidating the capture with an opaque HIP error."""
+    import dietgpu_amd
+    from dietgpu_amd import ops
+
+    dietgpu_amd.lib()
+    dev = torch.device("cuda", 0)
+    x = (torch.arange(50_000, device=dev) % 37).to(torch.uint8)
+    comp, sizes, _ = ops.compress_data(False, [x], True)
+    out = torch.empty_like(x)
+    ops.decompress_data(False, [comp[0]], [out], True)  # plain call: fine
+    assert torch.equal(out, x)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    failed = None
+    try:
+        with torch.cuda.graph(graph, stream=s):
+            ops.decompress_data(False, [comp[0]], [out], True)
+    except Exception as e:
+        failed = str(e)
+    assert failed is not None and "checksum verification" in failed, failed
+    torch.cuda.synchronize()
+    out.zero_()
+    ops.decompress_data(False, [comp[0]], [out], True)  # the library is usable afterwards
+    assert torch.equal(out, x)

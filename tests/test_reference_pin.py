@@ -255,3 +255,58 @@ def test_stride_and_split_size_providers_of_the_reference():
             assert same(r, O.float_compress(ft, w, 10), mask_float), ft
         outs, ok, osz, rc = R.float_decompress_split_size(ft, [O.float_compress(ft, w, 10) for w in ws], [w.size for w in ws], 10)
         assert rc == 0 and ok.all() and all((o == w).all() for o, w in zip(outs, ws))
+
+
+def _hist_variants(x):
+    """Caller-supplied histograms that COVER the data (every present symbol has a non-zero count): the exact counts,
+    the counts x 3 (the normalisation's deficit branch: the quantised sum comes out near 3 x 2^P), the counts + 1 on
+    every bin (symbols the data does not hold get probability mass), a flat histogram."""
+    c = np.bincount(x, minlength=256).astype(np.uint32)
+    return {"exact": c, "x3": c * 3, "plus1": c + 1, "flat": np.full(256, 7, np.uint32)}
+
+
+@pytest.mark.parametrize("prob_bits", [9, 10, 11])
+def test_caller_supplied_histogram_of_the_reference(prob_bits):
+    # `histogram_dev` of ansEncodeBatch{Pointer,Stride,SplitSize} (GpuANSCodec.h:65-164, GpuANSEncode.cuh:692-700): the
+    # reference normalises the counts it is GIVEN against the element's size.  The oracle's `counts=` does the same:
+    # byte-identical archives for every covering histogram, through all three batch providers, and they decode.
+    rows = [refgen.generate_symbols(n, lam) for n, lam in ((4096 * 3 + 100, 10.0), (4096 * 3 + 100, 100.0), (4096 * 3 + 100, 3.0))]
+    for name in ("exact", "x3", "plus1", "flat"):
+        counts = np.stack([_hist_variants(r)[name] for r in rows])
+        want = [O.ans_encode(r, prob_bits, use_checksum=True, counts=c) for r, c in zip(rows, counts)]
+        for provider in ("pointer", "stride", "split_size"):
+            got = R.ans_encode_batch_hist(rows, counts, prob_bits, True, provider)
+            for g, w in zip(got, want):
+                assert same(g, w, mask_ans), (name, provider)
+        if name == "exact":
+            for r, w in zip(rows, want):
+                assert (w == O.ans_encode(r, prob_bits, use_checksum=True)).all()
+        outs, ok, osz, rc = R.ans_decode_batch(want, [len(r) for r in rows], prob_bits, True)
+        assert rc == 0 and ok.all() and all((o == r).all() for o, r in zip(outs, rows)), name
+    # ragged batch through the pointer and split-size providers (interior sizes multiples of 4), one empty element
+    rows = [refgen.generate_symbols(n, 20.0) for n in (4096 + 8, 0, 100, 4096 * 2)]
+    counts = np.stack([np.bincount(r, minlength=256) + 1 for r in rows]).astype(np.uint32)
+    want = [O.ans_encode(r, prob_bits, counts=c) for r, c in zip(rows, counts)]
+    for provider in ("pointer", "split_size"):
+        for g, w in zip(R.ans_encode_batch_hist(rows, counts, prob_bits, False, provider), want):
+            assert same(g, w, mask_ans), provider
+
+
+def test_compressed_info_entry_points_of_the_reference():
+    # ansGetCompressedInfo(Device) / floatGetCompressedInfo(Device) (GpuANSCodec.h:309-341, GpuFloatCodec.h:252-292)
+    # read what the oracle's info functions read, on oracle archives
+    xs = [refgen.generate_symbols(n, 30.0) for n in (0, 1, 4096, 12345)]
+    arch = [O.ans_encode(x, 10, use_checksum=True) for x in xs]
+    for device in (False, True):
+        sizes, ck = R.ans_get_compressed_info(arch, want_checksum=True, device=device)
+        assert sizes.tolist() == [x.size for x in xs]
+        assert ck.tolist() == [O.ans_info(a)["checksum"] for a in arch] == [O.checksum(x) for x in xs]
+        sizes, ck = R.ans_get_compressed_info([O.ans_encode(x, 11) for x in xs], device=device)
+        assert sizes.tolist() == [x.size for x in xs] and ck is None
+    for ft in (O.FLOAT16, O.BFLOAT16, O.FLOAT32):
+        ws = [refgen.generate_floats(ft, n) for n in (0, 5, 4096 + 3)]
+        arch = [O.float_compress(ft, w, 10, use_checksum=True) for w in ws]
+        for device in (False, True):
+            sizes, types, ck = R.float_get_compressed_info(arch, want_checksum=True, device=device)
+            assert sizes.tolist() == [w.size for w in ws] and types.tolist() == [ft] * 3
+            assert ck.tolist() == [O.float_info(a)["checksum"] for a in arch]
