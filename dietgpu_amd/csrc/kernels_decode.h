@@ -289,7 +289,33 @@ __host__ __device__ constexpr uint32_t decLdsBytes(int P, uint32_t ft, uint32_t 
 // kNoRing (kFull): both blocks of the wave have <= 1024 compressed words (every exponent block of N(0,1)
 // bf16 has ~650), so the whole block is staged once and the ring maintenance, the wrap mask and the base OR
 // disappear from the row loop (the base is folded into the scalar positions).
-template <int P, uint32_t FT, bool kFull, bool kWide = false, bool kIdleUpper = false, bool kCompact = false, bool kNoRing = false>
+// Loads a workgroup issues BEFORE it builds its LUT, so that their round trip to memory overlaps with the build instead
+// of following it (k_ans_decode: header -> {pdf, block descriptor, lane states} -> {compressed words, first
+// non-compressed bytes} was a chain of four dependent round trips at the start of every workgroup; on cold buffers
+// that is 10-15 % of a workgroup's life).  Held in registers across the build; valid for whole-block staging only.
+struct DecodePre {
+  uint4 words[4];  // the block's compressed words, 16 bytes per lane and k (kNoRing)
+  uint2 nc[2];     // non-compressed bytes of the last two groups (join at the flush)
+};
+template <uint32_t FT>
+__device__ __forceinline__ void decodePrefetch(DecodePre& pre, const uint8_t* __restrict__ gwords, uint32_t numWords,
+                                               const RowSink<FT>& sink, uint32_t hl, bool wide) {
+  const uint32_t paddedBytes = roundUp(numWords, kBlockAlignWords) * 2u;
+#pragma unroll
+  for (uint32_t k = 0; k < 4u; ++k) {
+    const uint32_t off = (k * 32u + hl) * 16u;
+    pre.words[k] = make_uint4(0, 0, 0, 0);
+    if (off < paddedBytes) pre.words[k] = decLoad16(gwords + off);
+  }
+  pre.nc[0] = pre.nc[1] = make_uint2(0, 0);
+  if (wide) {
+    pre.nc[0] = sink.prefetchGroup(kRowsPerBlock / 8u - 1u, hl);
+    pre.nc[1] = sink.prefetchGroup(kRowsPerBlock / 8u - 2u, hl);
+  }
+}
+
+template <int P, uint32_t FT, bool kFull, bool kWide = false, bool kIdleUpper = false, bool kCompact = false, bool kNoRing = false,
+          bool kPre = false>
 __device__ __forceinline__ void decodeBlock(
     uint32_t xpose,                // kWide: LDS address of this half's transposition buffer
     uint32_t state,
@@ -302,7 +328,9 @@ __device__ __forceinline__ void decodeBlock(
     const void* __restrict__ lutRaw, // LDS: uint2 entries, or uint32 entries (kCompact)
     const RowSink<FT>& sink,
     uint32_t hl,
-    bool upper) {
+    bool upper,
+    const DecodePre* pre = nullptr) {  // kPre: the staging loads were issued by the caller (decodePrefetch)
+  static_assert(!kPre || (kNoRing && kFull), "");
   constexpr uint32_t kMask = (1u << P) - 1u;
   const uint32_t laneMaskLt = (1u << hl) - 1u;
   // LUT entry of slot x as {pdf | sym << 24, x - cdf} (the compact form is unpacked here)
@@ -327,8 +355,12 @@ __device__ __forceinline__ void decodeBlock(
 #pragma unroll
     for (uint32_t k = 0; k < 4u; ++k) {
       const uint32_t off = (k * 32u + hl) * 16u;
-      v[k] = make_uint4(0, 0, 0, 0);
-      if (off < paddedBytes) v[k] = decLoad16(gwords + off);
+      if (kPre) {
+        v[k] = pre->words[k];
+      } else {
+        v[k] = make_uint4(0, 0, 0, 0);
+        if (off < paddedBytes) v[k] = decLoad16(gwords + off);
+      }
     }
 #pragma unroll
     for (uint32_t k = 0; k < 4u; ++k) {
@@ -405,7 +437,8 @@ __device__ __forceinline__ void decodeBlock(
     return e.x;
   };
 
-  // Non-compressed bytes are fetched one whole group ahead.
+  // Non-compressed bytes are fetched ahead of their use: TWO groups on the wide path (a group takes ~1.5 us with three
+  // workgroups per CU -- one group ahead did not cover the latency of HBM under load on cold buffers), one otherwise.
   //  * wide path: ONE 8-byte load per lane and group -- the 8 consecutive bytes that belong to the 8 consecutive
   //    words the lane stores; they meet the decoded symbols only at the flush (RowSink::flushGroup), so a row
   //    costs no VALU for the join and no byte load;
@@ -415,8 +448,16 @@ __device__ __forceinline__ void decodeBlock(
   constexpr bool kJoinAtFlush = kFull && kWide;
   Pre preCur[kGroupRows], preNext[kGroupRows];
   const int lastGroup = (int)groups - 1;
-  uint2 ncCur = make_uint2(0, 0), ncNext = make_uint2(0, 0);
-  if (kJoinAtFlush) ncCur = sink.prefetchGroup((uint32_t)lastGroup, hl);
+  uint2 ncCur = make_uint2(0, 0), ncNext = make_uint2(0, 0), ncNext2 = make_uint2(0, 0);
+  if (kJoinAtFlush) {
+    if (kPre) {
+      ncCur = pre->nc[0];
+      ncNext = pre->nc[1];
+    } else {
+      ncCur = sink.prefetchGroup((uint32_t)lastGroup, hl);
+      ncNext = sink.prefetchGroup(lastGroup > 0 ? (uint32_t)(lastGroup - 1) : 0u, hl);
+    }
+  }
 #pragma unroll
   for (int j = 0; j < (int)kGroupRows; ++j) {
     const uint32_t row = (uint32_t)lastGroup * kGroupRows + j;
@@ -427,7 +468,7 @@ __device__ __forceinline__ void decodeBlock(
   for (int g = lastGroup; g >= 0; --g) {
     const uint32_t gNext = g > 0 ? (uint32_t)(g - 1) : 0u;
     if (kJoinAtFlush) {
-      ncNext = sink.prefetchGroup(gNext, hl);
+      ncNext2 = sink.prefetchGroup(g > 1 ? (uint32_t)(g - 2) : 0u, hl);
     } else {
 #pragma unroll
       for (int j = 0; j < (int)kGroupRows; ++j) {
@@ -468,6 +509,7 @@ __device__ __forceinline__ void decodeBlock(
     if (kJoinAtFlush) {
       if (!kIdleUpper || !upper) sink.flushGroup(xpose, (uint32_t)g, hl, ncCur);
       ncCur = ncNext;
+      ncNext = ncNext2;
     } else {
 #pragma unroll
       for (int j = 0; j < (int)kGroupRows; ++j) preCur[j] = preNext[j];
@@ -566,6 +608,50 @@ __global__ __launch_bounds__(decThreads(kTileBlocks)) void k_ans_decode(DecodeAr
     for (uint32_t i = tid; i < nb; i += kDecThreads) allBlocksOk = allBlocksOk && blockOk(i, blockWords[i]);
   }
 
+  // This half-wave's block descriptor and lane states and (wave 0) the pdf table are requested NOW, in the same round
+  // trip as tile 0's descriptor checks; as soon as the descriptor is there the block's compressed words and its first
+  // non-compressed bytes are requested too (decodePrefetch), and all of it lands while the LUT is being built.
+  const uint32_t block = tile * kTileBlocks + hw;
+  bool haveBlock = block < nb;
+  uint2 bwMine = make_uint2(0u, 0u);
+  uint32_t state = 0;
+  if (haveBlock) {
+    bwMine = blockWords[block];
+    state = ((const uint32_t*)(ans + ansStatesOffset()))[block * 32u + hl];  // (inside the archive: nb was checked against inBytes)
+  }
+  uint2 pdfRaw = make_uint2(0u, 0u);
+  if (wave == 0) pdfRaw = ((const uint2*)(ans + sizeof(AnsHeader)))[lane];  // pdf[4 lane .. 4 lane + 3]
+  uint32_t n = 0, numWords = 0, start = 0;
+  if (haveBlock) {
+    if (blockOk(block, bwMine)) {
+      n = bwMine.x >> 16;
+      numWords = bwMine.x & 0xffffu;
+      start = bwMine.y;
+    } else {
+      haveBlock = false;  // malformed block: neither read nor written (tile 0 reports the element)
+      state = 0;
+    }
+  }
+  const uint8_t* gwords = ans + ansOverhead(nb) + 2u * (size_t)start;
+  RowSink<FT> sink;
+  // (a half without a block points at its wave's first block: its prefetches must stay inside the archive)
+  sink.init(a.out.ptr(b), archive, floatSize, (size_t)(haveBlock ? block : (block & ~1u)) * kBlockSize, hl);
+  // LDS address of the dynamic segment (0: this kernel has no static LDS); the
+  // rings must be 2 KiB aligned for the and-or addressing in decodeBlock
+  const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+  // uniform per wave: both halves hold full blocks?  small enough to be staged whole?
+  const uint32_t nFirst = __shfl(n, 0, 64);
+  const uint32_t nSecond = __shfl(n, 32, 64);
+  const uint32_t wFirst = __shfl(numWords, 0, 64);
+  const uint32_t wSecond = __shfl(numWords, 32, 64);
+  const bool noRing = wFirst <= kRingBytes / 2u && wSecond <= kRingBytes / 2u;
+  const bool wide = decXposeBytes(P, FT, kTileBlocks) != 0 && (((uintptr_t)a.out.ptr(b)) & 15u) == 0;  // wide stores need a 16-byte aligned output element
+  const bool fullPair = nFirst == kBlockSize && nSecond == kBlockSize;
+  // one full block in the wave (odd block counts): fast path with an idle upper half
+  const bool fullSingle = nFirst == kBlockSize && nSecond == 0u;
+  DecodePre pre;
+  if ((fullPair || fullSingle) && noRing) decodePrefetch<FT>(pre, gwords, numWords, sink, hl, wide);
+
   // Decode LUT, built by the workgroup itself from the archive's pdf table (no
   // separate table kernel / LUT round trip through HBM):
   //   lut[x] = { pdf[sym] | sym << 24,  x - cdf[sym] },  sym = symbol whose cdf range holds x
@@ -595,7 +681,7 @@ __global__ __launch_bounds__(decThreads(kTileBlocks)) void k_ans_decode(DecodeAr
       for (uint32_t i = tid; i < (1u << P) / 4u; i += kDecThreads) ((uint32_t*)sMark)[i] = 0u;
     }
     if (wave == 0) {
-      const uint2 raw = ((const uint2*)(ans + sizeof(AnsHeader)))[lane];  // pdf[4 lane .. 4 lane + 3]
+      const uint2 raw = pdfRaw;
       const uint32_t p0 = raw.x & 0xffffu, p1 = raw.x >> 16, p2 = raw.y & 0xffffu, p3 = raw.y >> 16;
       const uint32_t mine = p0 + p1 + p2 + p3;
       const uint32_t incl = waveInclusiveScan(mine, lane);
@@ -673,51 +759,20 @@ __global__ __launch_bounds__(decThreads(kTileBlocks)) void k_ans_decode(DecodeAr
     }
   }
 
-  const uint32_t block = tile * kTileBlocks + hw;
-  bool haveBlock = block < nb;
-
-  uint32_t state = 0, n = 0, numWords = 0, start = 0;
-  if (haveBlock) {
-    const uint2 bw = blockWords[block];
-    if (blockOk(block, bw)) {
-      state = ((const uint32_t*)(ans + ansStatesOffset()))[block * 32u + hl];
-      n = bw.x >> 16;
-      numWords = bw.x & 0xffffu;
-      start = bw.y;
-    } else {
-      haveBlock = false;  // malformed block: neither read nor written (tile 0 has reported the element)
-    }
-  }
-  const uint8_t* gwords = ans + ansOverhead(nb) + 2u * (size_t)start;
   __syncthreads();  // LUT visible to every wave, scratch free (each half-wave's ring is private to its wave)
 
-  RowSink<FT> sink;
-  // (a half without a block points at its wave's first block: its prefetches must stay inside the archive)
-  sink.init(a.out.ptr(b), archive, floatSize, (size_t)(haveBlock ? block : (block & ~1u)) * kBlockSize, hl);
-  // LDS address of the dynamic segment (0: this kernel has no static LDS); the
-  // rings must be 2 KiB aligned for the and-or addressing in decodeBlock
-  const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
-
-  // uniform per wave: both halves hold full blocks?
-  const uint32_t nFirst = __shfl(n, 0, 64);
-  const uint32_t nSecond = __shfl(n, 32, 64);
-  const uint32_t slot = hw < kTileBlocks ? hw : kTileBlocks - 1u;  // (single-block tiles: the idle upper half maps to slot 0 and touches nothing)
-  const uint32_t xpose = ldsBase + kTileBlocks * kRingBytes + kLutBytes + slot * kXpose;
-  const bool wide = kXpose != 0 && (((uintptr_t)a.out.ptr(b)) & 15u) == 0;  // wide stores need a 16-byte aligned output element
-  // both blocks of the wave small enough to be staged whole (wave-uniform)?
-  const uint32_t wFirst = __shfl(numWords, 0, 64);
-  const uint32_t wSecond = __shfl(numWords, 32, 64);
-  const bool noRing = wFirst <= kRingBytes / 2u && wSecond <= kRingBytes / 2u;
+  constexpr uint32_t kLutBytesHere = decLutBytes(P, kTileBlocks);
+  const uint32_t xpose = ldsBase + kTileBlocks * kRingBytes + kLutBytesHere + hw * kXpose;
+  const uint32_t ringLds = ldsBase + hw * kRingBytes;
 #define DGPU_DECODE_FULL(WIDE, IDLE, NORING) \
-  decodeBlock<P, FT, true, WIDE, IDLE, kCompact, NORING>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ldsBase + slot * kRingBytes, sLut, sink, hl, upper)
-  if (nFirst == kBlockSize && nSecond == kBlockSize) {
+  decodeBlock<P, FT, true, WIDE, IDLE, kCompact, NORING, NORING>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ringLds, sLut, sink, hl, upper, &pre)
+  if (fullPair) {
     if (wide) {
       if (noRing) DGPU_DECODE_FULL(true, false, true); else DGPU_DECODE_FULL(true, false, false);
     } else {
       if (noRing) DGPU_DECODE_FULL(false, false, true); else DGPU_DECODE_FULL(false, false, false);
     }
-  } else if (nFirst == kBlockSize && nSecond == 0u) {
-    // one full block in the wave (batches of single-block elements, odd block counts): fast path, idle upper half
+  } else if (fullSingle) {
     if (wide) {
       if (noRing) DGPU_DECODE_FULL(true, true, true); else DGPU_DECODE_FULL(true, true, false);
     } else {
@@ -726,7 +781,7 @@ __global__ __launch_bounds__(decThreads(kTileBlocks)) void k_ans_decode(DecodeAr
 #undef DGPU_DECODE_FULL
   } else {
     const uint32_t maxN = nFirst > nSecond ? nFirst : nSecond;
-    decodeBlock<P, FT, false, false, false, kCompact>(xpose, state, n, divUp(divUp(maxN, 32u), kGroupRows), gwords, numWords, smem, ldsBase + slot * kRingBytes, sLut, sink, hl, upper);
+    decodeBlock<P, FT, false, false, false, kCompact>(xpose, state, n, divUp(divUp(maxN, 32u), kGroupRows), gwords, numWords, smem, ringLds, sLut, sink, hl, upper);
   }
 }
 
