@@ -234,7 +234,7 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-TRAFFIC_FILES = ("r03_hbm_traffic.json", "r02_hbm_traffic.json")
+TRAFFIC_FILES = ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json")
 
 
 def measured_traffic(workload, kernel):
@@ -294,6 +294,9 @@ def cpu_baseline(kind, prob_bits, budget_s=12.0):
         except (OSError, ValueError):
             pass
     cores = max(1, min(visible, int(quota))) if quota else visible
+    # under a quota the threads are left to the scheduler: pinning 16 threads to the first 16 of 256 shared CPUs put them
+    # where other tenants already ran (9.5 GB/s at 5.6 CPU-seconds per wall-second against 11.5 GB/s at 15.2 unpinned)
+    pin = 0 if (quota and quota < visible) else 1
     rows = max(2 * cores, 16)
     n = 512 * 1024
     if kind == "u8":
@@ -314,7 +317,7 @@ def cpu_baseline(kind, prob_bits, budget_s=12.0):
     def run(nrows, threads, budget):
         def call(reps):
             e, d, bad = C.c_double(0), C.c_double(0), C.c_int(-1)
-            rc = L.dgo_bench_roundtrip(ft, data.ctypes.data, size, row_bytes, nrows, prob_bits, threads, reps, 1,
+            rc = L.dgo_bench_roundtrip(ft, data.ctypes.data, size, row_bytes, nrows, prob_bits, threads, reps, pin,
                                        C.byref(e), C.byref(d), C.byref(bad))
             assert rc == 0 and bad.value == 0, "CPU oracle round trip failed"
             return e.value, d.value
@@ -337,8 +340,8 @@ def cpu_baseline(kind, prob_bits, budget_s=12.0):
         "unit": "GB/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{rows} rows of the same workload x {reps} reps, oracle/ C restatement, {cores} persistent pinned "
-                  f"pthreads (rows b, b + {cores}, ... per thread), buffers pre-touched; encode {allc_enc:.3f} GB/s, "
+        "sample": f"{rows} rows of the same workload x {reps} reps, oracle/ C restatement, {cores} persistent "
+                  f"{'pinned ' if pin else ''}pthreads (rows b, b + {cores}, ... per thread), buffers pre-touched; encode {allc_enc:.3f} GB/s, "
                   f"decode {allc_dec:.3f} GB/s",
         "speedup_over_one_thread": round(allc / one, 1) if one else None,
         "host": {"visible_cpus": visible, "cgroup_cpu_quota": quota, "cpu_seconds_per_wall_second": round(granted, 1),

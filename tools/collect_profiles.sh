@@ -6,10 +6,10 @@ strip() { grep -a -v "amdgpu.ids\|^RCCL version\|^HIP version\|^ROCm version\|^H
 for f in gpurun_out/${T}_bench_*.json gpurun_out/${T}_reference_protocol.json; do
   [ -f "$f" ] && strip "$f" | grep -a "^{" | tail -1 > profiles/$(basename $f)
 done
-for f in api_rate graph_rate rotating_phases pytest; do
+for f in api_rate graph_rate pytest valu_rate traffic_summary; do
   [ -f gpurun_out/${T}_$f.txt ] && strip gpurun_out/${T}_$f.txt > profiles/${T}_$f.txt
 done
-for w in bf16 u8 fp16 fp32; do
+for w in bf16 u8 fp16 fp32; do  # (fp32 has bench lines only)
   [ -f gpurun_out/rocprof_${T}_$w.txt ] && strip gpurun_out/rocprof_${T}_$w.txt > profiles/${T}_rocprof_stats_$w.txt
   [ -f gpurun_out/rocprof_${T}one_$w.txt ] && strip gpurun_out/rocprof_${T}one_$w.txt > profiles/${T}_rocprof_stats_${w}_one_buffer_set.txt
   [ -f gpurun_out/pmc_${T}_$w.txt ] && strip gpurun_out/pmc_${T}_$w.txt > profiles/${T}_pmc_$w.txt

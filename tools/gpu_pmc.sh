@@ -5,7 +5,7 @@ TAG=${1:-run}; WL=${2:-bf16}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/gpurun_out /tmp/pmc_$TAG
-BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --workload $WL $PMC_ARGS"
+BENCH="python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --timeline --workload $WL $PMC_ARGS"
 i=0
 for set in \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
