@@ -654,6 +654,9 @@ def main():
         free_b = torch.cuda.mem_get_info(device)[0]
         per_set = codec.in_bytes * 2 + codec.comp.numel()
         rot_sets = int(max(1, min(args.rotate, (free_b - (2 << 30)) // max(per_set, 1) + 1)))
+        if distributed:
+            # every rank runs the same sequence of timed loops (their fences are collectives): agree on the set count
+            rot_sets = int(-D.max_over_ranks(-float(rot_sets), device))
         for r in range(1, rot_sets):
             d2, _, _, _, _ = make_workload(args.workload, args.batch, 1234 + rank + 1000 * r, device, args.elems)
             c2 = Codec(dg, d2, ft, prob_bits)
