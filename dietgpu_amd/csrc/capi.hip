@@ -966,7 +966,15 @@ int encodeCommon(
   }
 
 
-  DGPU_ALLOC(table, uint4, arena, (size_t)B * kNumSymbols);
+  // Encoder tables [B][256] x 16 bytes, normalisation -> encoder.  Not for batches of single-block elements: there
+  // the table would be as many bytes as the element's symbols, and k_ans_encode_pair derives it from the pdf table in
+  // the archive header instead.
+  const uint32_t tileBlocks = encTileBlocksFor(maxSize);
+  uint4* table = nullptr;
+  if (tileBlocks != kBlocksPerSingleTile) {
+    DGPU_ALLOC(tb, uint4, arena, (size_t)B * kNumSymbols);
+    table = tb;
+  }
   DGPU_ALLOC(tileDesc, uint64_t, arena, (size_t)B * std::max(maxTiles, 1u));
   DGPU_ALLOC(claims, uint32_t, arena, (size_t)B * std::max(maxTiles, 1u));
 
@@ -1045,7 +1053,6 @@ int encodeCommon(
     DGPU_HIP(hipGetLastError());
   }
   if (maxTiles > 0) {
-    const uint32_t tileBlocks = encTileBlocksFor(maxSize);
     const uint32_t grid = encodeGrid(P, floatType, tileBlocks, B * maxTiles);
     uint16_t* spill = nullptr;
     if (encodeSpills(floatType)) {

@@ -105,7 +105,7 @@ constexpr uint64_t kDescValueMask = (1ull << 62) - 1;
 struct EncodeArgs {
   BatchView in;              // raw bytes (FT == 0) or float words (FT != 0); size(b) = symbols = bytes / words
   BatchView out;             // archive base pointers
-  const uint4* encTable;     // [B][256] from k_normalize
+  const uint4* encTable;     // [B][256] from the normalisation; null for k_ans_encode_pair (builds its own from the pdf)
   uint32_t maxTiles;         // tiles per element the ticket space is laid out for
   uint32_t numInBatch;       // B
   uint32_t numTickets;       // B * maxTiles

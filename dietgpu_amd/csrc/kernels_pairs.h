@@ -86,12 +86,27 @@ __global__ __launch_bounds__(64) void k_ans_encode_pair(EncodeArgs a) {
     const uint32_t b = have ? (upper ? bHi : bLo) : (sLo ? bLo : bHi);
     const uint32_t esize = have ? n : (sLo ? sLo : sHi);
 
-#pragma unroll
-    for (uint32_t i = 0; i < kNumSymbols / 32u; ++i) sTable[i * 32u + hl] = a.encTable[(size_t)b * kNumSymbols + i * 32u + hl];
-
     const uint8_t* in = a.in.ptr(b);
     uint8_t* archive = a.out.ptr(b);
     uint8_t* ans = archive + ansOffsetInArchive(FT, esize);
+
+    // This half's encoder table, from the 512-byte pdf table the normalisation left in the archive header (8
+    // symbols per lane).  A [B][256] x 16-byte table in HBM between the two kernels would be as many bytes as the
+    // exponent plane of a 4 Ki element, written once and read once.
+    {
+      const uint4 raw = ((const uint4*)(ans + sizeof(AnsHeader)))[hl];  // pdf[8 hl .. 8 hl + 7]
+      const uint32_t pdf[8] = {raw.x & 0xffffu, raw.x >> 16, raw.y & 0xffffu, raw.y >> 16,
+                               raw.z & 0xffffu, raw.z >> 16, raw.w & 0xffffu, raw.w >> 16};
+      uint32_t mine = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mine += pdf[j];
+      uint32_t cdf = halfInclusiveScanDpp(mine) - mine;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        sTable[8u * hl + (uint32_t)j] = encTableEntry(pdf[j], cdf, P);
+        cdf += pdf[j];
+      }
+    }
 
     if (FT != 0 && have) {
       // GpuFloatHeader (GpuFloatCompress.cuh:325-337) and the zero padding of the non-comp plane(s) up to 16 bytes
@@ -223,32 +238,48 @@ __global__ __launch_bounds__(64) void k_ans_decode_pair(DecodeArgs a) {
     const bool fhOk = fh.magicAndVersion == ((kFloatMagic << 16) | kFloatVersion) && (fh.options & 0xfu) == FT &&
         fh.size <= a.out.size(b) &&
         (uint64_t)sizeof(FloatHeader) + floatUncompDataSize(FT, fh.size) + sizeof(AnsHeader) <= inBytes;
+    floatSize = fh.size;
     if (!fhOk) fail(fh.size);
   }
+  // Everything at a fixed offset from the start of the ANS archive is requested in ONE round trip: the header, the
+  // pdf table (8 probabilities per lane) and the descriptor and lane states of the element's block -- a valid archive
+  // of a non-empty element has exactly one block here (capacity <= 4096).  Descriptor and states are requested early
+  // only where they are known to lie inside the caller's buffer: the float header says that the element is not empty,
+  // or the caller said how many bytes there are; otherwise (raw ANS archives of unknown extent) after the header.  A
+  // load that is not to be made yet reads the first bytes of the header again.  (Before: header -> {descriptor, pdf}
+  // -> [LUT build] -> {states, words} = four dependent round trips per element with three wavefronts per SIMD to hide
+  // them.)
+  uint2 bw = make_uint2(0u, 0u);
+  uint4 rawPdf = make_uint4(0u, 0u, 0u, 0u);
+  uint32_t state = 0;
   if (live) {
-    ans = locateAns(archive, FT, &floatSize);
+    const uint32_t ansOff = ansOffsetInArchive(FT, floatSize);
+    ans = archive + ansOff;
+    const bool pdfThere = (uint64_t)ansOff + ansOverhead(0u) <= inBytes;
+    const bool early = (uint64_t)ansOff + ansOverhead(1u) <= inBytes && (FT ? floatSize != 0u : inBytes != ~0ull);
     const AnsHeader header = *(const AnsHeader*)ans;
+    rawPdf = *(const uint4*)(pdfThere ? ans + sizeof(AnsHeader) + 16u * hl : ans);  // pdf[8 hl .. 8 hl + 7]
+    bw = *(const uint2*)(early ? ans + ansBlockWordsOffset(1u) : ans);
+    state = *(const uint32_t*)(early ? ans + ansStatesOffset() + 4u * hl : ans);
     nb = header.numBlocks;
     total = header.totalUncompressedWords;
     totalWords = header.totalCompressedWords;
-    bool success = a.out.size(b) >= total;
+    bool success = a.out.size(b) >= total && pdfThere;
     success = success && header.magicAndVersion == ((kAnsMagic << 16) | kAnsVersion) &&
         (header.options & 0xfu) == (uint32_t)P;
     if (FT) success = success && floatSize == total;
     success = success && nb == divUp(total, kBlockSize);
     success = success && (uint64_t)ansOffsetInArchive(FT, total) + ansOverhead(nb) + 2ull * totalWords <= inBytes;
     if (!success) fail(total);
+    if (live && nb && !early) {
+      bw = *(const uint2*)(ans + ansBlockWordsOffset(nb));
+      state = ((const uint32_t*)(ans + ansStatesOffset()))[hl];
+    }
+    if (nb == 0u) bw = make_uint2(0u, 0u);
   }
-
-  // block descriptor and pdf table (8 probabilities per lane); the sum comes out of the cdf scan
-  uint2 bw = make_uint2(0u, 0u);
-  uint32_t pdf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (live) {
-    if (nb) bw = *(const uint2*)(ans + ansBlockWordsOffset(nb));
-    const uint4 raw = ((const uint4*)(ans + sizeof(AnsHeader)))[hl];  // pdf[8 hl .. 8 hl + 7]
-    pdf[0] = raw.x & 0xffffu; pdf[1] = raw.x >> 16; pdf[2] = raw.y & 0xffffu; pdf[3] = raw.y >> 16;
-    pdf[4] = raw.z & 0xffffu; pdf[5] = raw.z >> 16; pdf[6] = raw.w & 0xffffu; pdf[7] = raw.w >> 16;
-  }
+  if (!live) rawPdf = make_uint4(0u, 0u, 0u, 0u);
+  const uint32_t pdf[8] = {rawPdf.x & 0xffffu, rawPdf.x >> 16, rawPdf.y & 0xffffu, rawPdf.y >> 16,
+                           rawPdf.z & 0xffffu, rawPdf.z >> 16, rawPdf.w & 0xffffu, rawPdf.w >> 16};
   uint32_t mine = 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) mine += pdf[j];
@@ -272,6 +303,53 @@ __global__ __launch_bounds__(64) void k_ans_decode_pair(DecodeArgs a) {
     decodeMe = nb != 0u && blocksOk && pdfOk;
   }
   if (__ballot(decodeMe) == 0ull) return;  // uniform
+
+  // The set-up of the row loop does not depend on the LUT: it comes first, so that the block's compressed words and
+  // its first non-compressed bytes are requested (decodePrefetch) BEFORE the LUT is built and land during the build.
+  uint32_t n = 0, numWords = 0;
+  const uint8_t* gwords = nullptr;
+  uint8_t* outPtr = nullptr;
+  if (decodeMe) {
+    n = bw.x >> 16;
+    numWords = bw.x & 0xffffu;
+    gwords = ans + ansOverhead(nb) + 2u * (size_t)bw.y;
+    outPtr = a.out.ptr(b);
+  } else {
+    state = 0;
+  }
+  // a half with nothing to decode follows its neighbour's element (its prefetches must stay inside an archive)
+  {
+    const int other = (int)(lane ^ 32u);
+    const uint64_t oArchive = __shfl((unsigned long long)(uintptr_t)archive, other, 64);
+    const uint64_t oOut = __shfl((unsigned long long)(uintptr_t)outPtr, other, 64);
+    const uint64_t oWords = __shfl((unsigned long long)(uintptr_t)gwords, other, 64);
+    const uint32_t oFloatSize = __shfl(floatSize, other, 64);
+    if (!decodeMe) {
+      typedef __attribute__((address_space(1))) uint8_t* GlobalBytes;
+      archive = (const uint8_t*)(GlobalBytes)(uintptr_t)oArchive;
+      outPtr = (uint8_t*)(GlobalBytes)(uintptr_t)oOut;
+      gwords = (const uint8_t*)(GlobalBytes)(uintptr_t)oWords;
+      floatSize = oFloatSize;
+    }
+  }
+
+  RowSink<FT> sink;
+  sink.init(outPtr, archive, floatSize, 0, hl);
+  const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+  const uint32_t ringBase = ldsBase + half * kRingBytes;
+  const uint32_t xpose = ldsBase + 2u * kRingBytes + 2u * kLutBytes + half * kXpose;
+  const uint32_t nLo = __shfl(n, 0, 64);
+  const uint32_t nHi = __shfl(n, 32, 64);
+  const uint32_t wLo = __shfl(numWords, 0, 64);
+  const uint32_t wHi = __shfl(numWords, 32, 64);
+  // wide stores need 16-byte aligned output elements
+  const bool wide = kXpose != 0 && __ballot((((uintptr_t)outPtr) & 15u) != 0) == 0ull;
+  const bool fullBoth = nLo == kBlockSize && nHi == kBlockSize;
+  // both blocks small enough to be staged whole (every exponent block of N(0,1) bf16 has ~650 words): the cheaper
+  // row loop of decodeBlock (kNoRing), fed by the prefetch
+  const bool noRing = wLo <= kRingBytes / 2u && wHi <= kRingBytes / 2u;
+  DecodePre pre;
+  if (fullBoth && noRing) decodePrefetch<FT>(pre, gwords, numWords, sink, hl, wide);
 
   if (decodeMe) {
     // cdf / pdf scratch and the symbol marks: mark[cdf[s]] = s for every present symbol
@@ -320,47 +398,15 @@ __global__ __launch_bounds__(64) void k_ans_decode_pair(DecodeArgs a) {
   }
   pairLdsFence();  // LUTs complete, scratch (= the rings) free
 
-  uint32_t state = 0, n = 0, numWords = 0;
-  const uint8_t* gwords = nullptr;
-  uint8_t* outPtr = nullptr;
-  if (decodeMe) {
-    state = ((const uint32_t*)(ans + ansStatesOffset()))[hl];
-    n = bw.x >> 16;
-    numWords = bw.x & 0xffffu;
-    gwords = ans + ansOverhead(nb) + 2u * (size_t)bw.y;
-    outPtr = a.out.ptr(b);
-  }
-  // a half with nothing to decode follows its neighbour's element (its prefetches must stay inside an archive)
-  {
-    const int other = (int)(lane ^ 32u);
-    const uint64_t oArchive = __shfl((unsigned long long)(uintptr_t)archive, other, 64);
-    const uint64_t oOut = __shfl((unsigned long long)(uintptr_t)outPtr, other, 64);
-    const uint64_t oWords = __shfl((unsigned long long)(uintptr_t)gwords, other, 64);
-    const uint32_t oFloatSize = __shfl(floatSize, other, 64);
-    if (!decodeMe) {
-      typedef __attribute__((address_space(1))) uint8_t* GlobalBytes;
-      archive = (const uint8_t*)(GlobalBytes)(uintptr_t)oArchive;
-      outPtr = (uint8_t*)(GlobalBytes)(uintptr_t)oOut;
-      gwords = (const uint8_t*)(GlobalBytes)(uintptr_t)oWords;
-      floatSize = oFloatSize;
-    }
-  }
-
-  RowSink<FT> sink;
-  sink.init(outPtr, archive, floatSize, 0, hl);
-  const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
-  const uint32_t ringBase = ldsBase + half * kRingBytes;
-  const uint32_t xpose = ldsBase + 2u * kRingBytes + 2u * kLutBytes + half * kXpose;
-  const uint32_t nLo = __shfl(n, 0, 64);
-  const uint32_t nHi = __shfl(n, 32, 64);
-  // wide stores need 16-byte aligned output elements
-  const bool wide = kXpose != 0 && __ballot((((uintptr_t)outPtr) & 15u) != 0) == 0ull;
-  if (nLo == kBlockSize && nHi == kBlockSize) {
+#define DGPU_PAIR_DECODE_FULL(WIDE, NORING) \
+  decodeBlock<P, FT, true, WIDE, false, true, NORING, NORING>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ringBase, sLut, sink, hl, upper, &pre)
+  if (fullBoth) {
     if (wide) {
-      decodeBlock<P, FT, true, true, false, true>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ringBase, sLut, sink, hl, upper);
+      if (noRing) DGPU_PAIR_DECODE_FULL(true, true); else DGPU_PAIR_DECODE_FULL(true, false);
     } else {
-      decodeBlock<P, FT, true, false, false, true>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ringBase, sLut, sink, hl, upper);
+      if (noRing) DGPU_PAIR_DECODE_FULL(false, true); else DGPU_PAIR_DECODE_FULL(false, false);
     }
+#undef DGPU_PAIR_DECODE_FULL
   } else {
     const uint32_t maxN = nLo > nHi ? nLo : nHi;
     decodeBlock<P, FT, false, false, false, true>(xpose, state, n, divUp(divUp(maxN, 32u), kGroupRows), gwords, numWords, smem, ringBase, sLut, sink, hl, upper);

@@ -64,6 +64,41 @@ __device__ __forceinline__ uint32_t waveInclusiveScanDpp(uint32_t v) {
 // c(v) = #{1 < q <= v} and takes the first entries with q == v* in symbol order (= ascending key).  ~300
 // wave-instructions instead of the 2300 of a 256 x 256 rank-by-counting (round 1), which made batches of
 // many small elements normalisation-bound.  The block scan is wave64 DPP.
+// Encoder table entry of one symbol.  The encoder needs q = floor(x / pdf) for states x < 2^31
+// (x >= 16 always): q = umulhi(x, m) >> sh with a 32-bit m, no add-back step
+// (the 33-bit "round-up" magic of the reference, GpuANSStatistics.cuh:349-358, is only needed
+// for full 32-bit dividends):
+//   pdf = 2^k, k >= 1: m = 2^(32-k), sh = 0                 (exact shift)
+//   otherwise, L = ceil(log2 pdf): m = floor(2^(31+L) / pdf) + 1, sh = L - 1
+//     (m < 2^32 because pdf > 2^(L-1); error term x * e / (pdf * 2^(31+L)) with
+//      e <= pdf < 2^L and x < 2^31 stays below 1 / pdf: the floor is exact)
+//   pdf = 1: m = 2^32 - 1 gives q = x - 1; the missing (2^P - 1) is added to
+//     the entry's cdf term instead
+// state' = x + cdf + q * (2^P - pdf).  The double division is exact enough:
+// the quotient is at least 2^-11 away from an integer, its error is < 2^-20.
+__device__ __forceinline__ uint4 encTableEntry(uint32_t pdf, uint32_t cdf, int P) {
+  const uint32_t W = 1u << P;
+  uint32_t m = 0, sh = 0, cdfTerm = cdf;
+  if (pdf == 1u) {
+    m = 0xffffffffu;
+    cdfTerm = cdf + (W - 1u);
+  } else if (pdf > 1u) {
+    const uint32_t L = 32u - (uint32_t)__clz((int)(pdf - 1u));  // ceil(log2 pdf)
+    if ((pdf & (pdf - 1u)) == 0u) {
+      m = 1u << (32u - L);
+    } else {
+      sh = L - 1u;
+      m = (uint32_t)(unsigned long long)floor(ldexp(1.0, 31 + (int)L) / (double)pdf) + 1u;
+    }
+  }
+  uint4 e;
+  e.x = pdf << (kStateBits - P);
+  e.y = m;
+  e.z = cdfTerm;
+  e.w = ((W - pdf) & 0xffffffu) | (sh << 24);
+  return e;
+}
+
 struct NormalizeArgs {
   BatchView sizes;           // only size(b) is used
   const uint32_t* hist;      // [B][histParts][256]: per-workgroup partial histograms, summed here
@@ -242,39 +277,7 @@ __device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const u
 
   }
 
-  if (a.encTable) {
-    // Encoder entry.  The encoder needs q = floor(x / pdf) for states x < 2^31
-    // (x >= 16 always): q = umulhi(x, m) >> sh with a 32-bit m, no add-back step
-    // (the 33-bit "round-up" magic of the reference, :349-358, is only needed
-    // for full 32-bit dividends):
-    //   pdf = 2^k, k >= 1: m = 2^(32-k), sh = 0                 (exact shift)
-    //   otherwise, L = ceil(log2 pdf): m = floor(2^(31+L) / pdf) + 1, sh = L - 1
-    //     (m < 2^32 because pdf > 2^(L-1); error term x * e / (pdf * 2^(31+L)) with
-    //      e <= pdf < 2^L and x < 2^31 stays below 1 / pdf: the floor is exact)
-    //   pdf = 1: m = 2^32 - 1 gives q = x - 1; the missing (2^P - 1) is added to
-    //     the entry's cdf term instead
-    // state' = x + cdf + q * (2^P - pdf).  The double division is exact enough:
-    // the quotient is at least 2^-11 away from an integer, its error is < 2^-20.
-    uint32_t m = 0, sh = 0, cdfTerm = cdf;
-    if (pdf == 1u) {
-      m = 0xffffffffu;
-      cdfTerm = cdf + (W - 1u);
-    } else if (pdf > 1u) {
-      const uint32_t L = 32u - (uint32_t)__clz((int)(pdf - 1u));  // ceil(log2 pdf)
-      if ((pdf & (pdf - 1u)) == 0u) {
-        m = 1u << (32u - L);
-      } else {
-        sh = L - 1u;
-        m = (uint32_t)(unsigned long long)floor(ldexp(1.0, 31 + (int)L) / (double)pdf) + 1u;
-      }
-    }
-    uint4 e;
-    e.x = pdf << (kStateBits - P);
-    e.y = m;
-    e.z = cdfTerm;
-    e.w = ((W - pdf) & 0xffffffu) | (sh << 24);
-    a.encTable[b * kNumSymbols + tid] = e;
-  }
+  if (a.encTable) a.encTable[b * kNumSymbols + tid] = encTableEntry(pdf, cdf, P);
   if (a.refTable) {
     // the reference's table (pdf, cdf, 33-bit magic, shift), :349-358
     uint32_t magic = 0, shift = 0;
