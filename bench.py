@@ -198,11 +198,13 @@ def algorithmic_bytes(kernel, codec, comp_total):
         ans = comp_total - 16 * codec.B - nc   # compressed exponent archives
         return {
             "k_float_histogram": E * wb,            # read the float words once
+            "k_stats_single": E * wb,               # (batches of single-block elements: one wavefront per element)
             "k_ans_encode": E * wb + nc + ans,      # read words, write non-comp plane + rANS archive (split fused in)
             "k_ans_decode": ans + nc + E * wb,      # read archive + non-comp plane, write words (join fused in)
         }.get(kernel)
     return {
         "k_histogram": E,
+        "k_stats_single": E,
         "k_ans_encode": E + comp_total,
         "k_ans_decode": comp_total + E,
     }.get(kernel)
@@ -787,7 +789,7 @@ def main():
 
         def direction(table):
             """compress = algorithmic bytes of the direction / (histogram + encode), decompress = ... / decode"""
-            hist = next((v["avg_us"] for k, v in table.items() if "histogram" in k), 0.0)
+            hist = next((v["avg_us"] for k, v in table.items() if "histogram" in k or "stats" in k), 0.0)
             enc = sum(v["avg_us"] for k, v in table.items() if k.startswith("k_ans_encode"))
             dec = sum(v["avg_us"] for k, v in table.items() if k.startswith("k_ans_decode"))
             frac = lambda us: round(dir_alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if us else None

@@ -999,7 +999,25 @@ int encodeCommon(
   n.claims = claims;
   n.numInBatch = B;
 
-  if (!hist_dev) {
+  if (!hist_dev && tileBlocks == kBlocksPerSingleTile && maxTiles > 0) {
+    // batches of single-block elements: one wavefront counts and normalises an element (kernels_pairs.h); no partial
+    // histograms, no arrival counters
+    const dim3 grid(divUp(B, 4u));
+#define DGPU_STATS_SINGLE(FT)                                                                                           \
+    if (histogramLoadsNonTemporal(floatType)) {                                                                         \
+      DGPU_LAUNCH("k_stats_single", stream, (k_stats_single<FT, true>), grid, dim3(256), 0, stream, in, n);             \
+    } else {                                                                                                            \
+      DGPU_LAUNCH("k_stats_single", stream, (k_stats_single<FT, false>), grid, dim3(256), 0, stream, in, n);            \
+    }
+    switch (floatType) {
+      case 0: DGPU_STATS_SINGLE(0u) break;
+      case kFloat16: DGPU_STATS_SINGLE(kFloat16) break;
+      case kBFloat16: DGPU_STATS_SINGLE(kBFloat16) break;
+      default: DGPU_STATS_SINGLE(kFloat32) break;
+    }
+#undef DGPU_STATS_SINGLE
+    DGPU_HIP(hipGetLastError());
+  } else if (!hist_dev) {
     const bool accumulate = histAccumulates(B, maxSize * wordBytes, floatType == 0);
     dim3 grid(accumulate ? histPartsAccFor(B, maxSize * wordBytes) : histPartsFor(B, maxSize * wordBytes, floatType == 0), B);
     uint32_t* histTemp = nullptr;

@@ -44,6 +44,119 @@ __device__ __forceinline__ uint32_t halfInclusiveMaxScanDpp(uint32_t v) {
 __device__ __forceinline__ void pairLdsFence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // ---------------------------------------------------------------------------
+// Statistics of single-block elements: ONE WAVEFRONT counts and normalises an element (k_histogram /
+// k_float_histogram + normalizeElement give it a 256-thread workgroup: six barriers and a quarter of the elements in
+// flight per CU for 8 KiB of input).  The wave loads the whole element with all its loads in flight, counts into its
+// own 8-slot bins, then lane l folds and normalises symbols 4 l .. 4 l + 3 -- the layout normDeficitTrips works on --
+// and writes the pdf table and the static header fields into the archive (what normalizeElement writes; the encoder
+// table is k_ans_encode_pair's business).  No barriers: the four waves of a workgroup are four elements.
+// Semantics: ansHistogramBatch + ansCalcWeights (GpuANSStatistics.cuh:43-367) per element.
+constexpr uint32_t kSingleStatSlots = 8;
+__host__ __device__ constexpr uint32_t statSingleLdsBytes() { return 4u * kNumSymbols * kSingleStatSlots * 4u; }
+
+template <uint32_t FT, bool kNt>
+__global__ __launch_bounds__(256) void k_stats_single(BatchView in, NormalizeArgs a) {
+  constexpr uint32_t S = kSingleStatSlots;
+  __shared__ __attribute__((aligned(16))) uint32_t sBins[4u * kNumSymbols * S];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t b = blockIdx.x * 4u + wave;
+  if (b >= a.numInBatch) return;  // wave-uniform; no barriers in this kernel
+
+  uint32_t* bins = sBins + wave * kNumSymbols * S;
+#pragma unroll
+  for (uint32_t i = 0; i < kNumSymbols * S / 4u / 64u; ++i) ((uint4*)bins)[i * 64u + lane] = make_uint4(0, 0, 0, 0);
+  uint32_t* myBins = histMine<S>(bins, lane);
+
+  const uint32_t n = in.size(b);  // symbols (bytes or float words), <= 4096: the host's guarantee
+  const uint8_t* p = in.ptr(b);
+  auto addWord = [&](uint32_t x) {  // the symbols of one 32-bit word of input
+    if (FT == 0) {
+      histAdd4<S>(myBins, x);
+    } else if (FT == kFloat32) {
+      histAdd<S>(myBins, (x >> 23) & 0xffu);
+    } else {
+      constexpr uint32_t kShift = FT == kFloat16 ? 8u : 7u;
+      histAdd<S>(myBins, (x >> kShift) & 0xffu);
+      histAdd<S>(myBins, (x >> (16u + kShift)) & 0xffu);
+    }
+  };
+  auto addOne = [&](uint32_t i) {  // symbol i on its own (heads, tails, unaligned elements)
+    uint32_t c;
+    if (FT == 0) c = p[i];
+    else if (FT == kFloat32) c = (((const uint32_t*)p)[i] >> 23) & 0xffu;
+    else c = ((uint32_t)((const uint16_t*)p)[i] >> (FT == kFloat16 ? 8u : 7u)) & 0xffu;
+    histAdd<S>(myBins, c);
+  };
+  constexpr uint32_t kSymBytes = FT == 0 ? 1u : (FT == kFloat32 ? 4u : 2u);
+  constexpr uint32_t kSymPerVec = 16u / kSymBytes;
+  // symbols before the first 16-byte boundary (raw bytes come at any alignment; float words that are not aligned to
+  // their own size cannot reach a boundary: the whole element then goes symbol by symbol)
+  const uint32_t mis = (uint32_t)((uintptr_t)p & 15u);
+  uint32_t head = ((16u - mis) & 15u) / kSymBytes;
+  if ((mis % kSymBytes) != 0u || head > n) head = n;
+  const uint32_t numVec = (n - head) / kSymPerVec;  // <= 256 (bytes), 512 (16-bit words), 1024 (float32)
+  const uint4* pv = (const uint4*)(p + (size_t)head * kSymBytes);
+  constexpr uint32_t kVecPerLane = 4096u / kSymPerVec / 64u;  // 4 / 8 / 16
+  constexpr uint32_t kBatch = kVecPerLane < 8u ? kVecPerLane : 8u;
+  pairLdsFence();  // bins zeroed (this wave's LDS operations execute in order; see pairLdsFence)
+#pragma unroll
+  for (uint32_t k0 = 0; k0 < kVecPerLane; k0 += kBatch) {
+    // a batch of loads in flight, then their symbols
+    uint4 x[kBatch];
+#pragma unroll
+    for (uint32_t k = 0; k < kBatch; ++k) {
+      const uint32_t v = (k0 + k) * 64u + lane;
+      x[k] = make_uint4(0, 0, 0, 0);
+      if (v < numVec) x[k] = streamLoad<kNt>(&pv[v]);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kBatch; ++k) {
+      if ((k0 + k) * 64u + lane < numVec) {
+        addWord(x[k].x);
+        addWord(x[k].y);
+        addWord(x[k].z);
+        addWord(x[k].w);
+      }
+    }
+  }
+  for (uint32_t i = lane; i < head; i += 64u) addOne(i);
+  for (uint32_t i = head + numVec * kSymPerVec + lane; i < n; i += 64u) addOne(i);
+  pairLdsFence();  // every count is in the bins
+
+  // ---- normalisation (normalizeElement's arithmetic; lane l = symbols 4 l .. 4 l + 3)
+  const int P = a.probBits;
+  const uint32_t W = 1u << P;
+  uint32_t pdf[4] = {0, 0, 0, 0};
+  if (n != 0u) {
+    uint32_t qSumMine = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j) {
+      const uint32_t count = histFold<S>(bins, 4u * lane + j);
+      // GpuANSStatistics.cuh:215-218, round-to-nearest divide and multiply as in normalizeElement
+      const float ratio = __fdiv_rn(__uint2float_rn(count), __uint2float_rn(n));
+      uint32_t q = __float2uint_rz(__fmul_rn(__uint2float_rn(W), ratio));
+      q = (count > 0u && q == 0u) ? 1u : q;
+      pdf[j] = q;
+      qSumMine += q;
+    }
+    const uint32_t qSum = __builtin_amdgcn_readlane(waveInclusiveScanDpp(qSumMine), 63);
+    const int diff = (int)W - (int)qSum;  // :256
+    if (diff >= 0) {  // uniform: the closed form of :258-274
+#pragma unroll
+      for (uint32_t j = 0; j < 4u; ++j) pdf[j] += (uint32_t)diff / 256u + ((4u * lane + j < ((uint32_t)diff % 256u)) ? 1u : 0u);
+    } else {
+      normDeficitTrips(pdf, (uint32_t)(-diff), W);
+    }
+  }
+
+  uint8_t* ans = a.out.ptr(b) + ansOffsetInArchive(a.floatType, n);
+  // pdf[4 l .. 4 l + 3] as four u16 (GpuANSEncode.cuh:568-573)
+  ((uint2*)(ans + sizeof(AnsHeader)))[lane] = make_uint2(pdf[0] | (pdf[1] << 16), pdf[2] | (pdf[3] << 16));
+  if (lane == 0u) normWriteHeader(a, b, n, ans);
+}
+
+// ---------------------------------------------------------------------------
 // Encoder.  LDS: two 4 KiB tables, two stages, two 512-byte symbol rings.  The two stages belong to different
 // ELEMENTS: the non-spilling ones are guarded (encodeRows, kGuard) and have kEncGuardSlackWords of room behind them.
 __host__ __device__ constexpr uint32_t encPairStageWords(int P, bool spill, uint32_t ft) {

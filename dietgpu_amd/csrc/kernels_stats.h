@@ -64,6 +64,78 @@ __device__ __forceinline__ uint32_t waveInclusiveScanDpp(uint32_t v) {
 // c(v) = #{1 < q <= v} and takes the first entries with q == v* in symbol order (= ascending key).  ~300
 // wave-instructions instead of the 2300 of a 256 x 256 rank-by-counting (round 1), which made batches of
 // many small elements normalisation-bound.  The block scan is wave64 DPP.
+
+// minimum over the 64 lanes of a wavefront (DPP row shifts / broadcasts; every lane receives it)
+__device__ __forceinline__ uint32_t waveMinDpp(uint32_t v) {
+  auto mn = [](uint32_t a, uint32_t b) { return a < b ? a : b; };
+  const int kId = (int)0xffffffffu;  // lanes without a source keep the identity
+  v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(kId, (int)v, 0x111, 0xf, 0xf, false));  // row_shr:1
+  v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(kId, (int)v, 0x112, 0xf, 0xf, false));  // row_shr:2
+  v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(kId, (int)v, 0x114, 0xf, 0xf, false));  // row_shr:4
+  v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(kId, (int)v, 0x118, 0xf, 0xf, false));  // row_shr:8
+  v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(kId, (int)v, 0x142, 0xa, 0xf, false));  // row_bcast:15 -> rows 1, 3
+  v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(kId, (int)v, 0x143, 0xc, 0xf, false));  // row_bcast:31 -> rows 2, 3
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// The deficit branch of the normalisation (GpuANSStatistics.cuh:275-315) on ONE wavefront: lane l holds the quantised
+// probabilities of symbols 4 l .. 4 l + 3 in qq[]; subtracts 1 from the smallest entries that are still > 1, trip
+// after trip, until `d` has been taken off the sum (see the header comment above for the selection by ballots).
+__device__ __forceinline__ void normDeficitTrips(uint32_t (&qq)[4], uint32_t d, const uint32_t W) {
+  // c(v) = number of entries with 1 < q <= v  (wave-uniform)
+  auto countUpTo = [&](uint32_t v) -> uint32_t {
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c += (uint32_t)__popcll(__ballot((qq[j] - 2u) <= (v - 2u)));
+    return c;
+  };
+  // smallest v >= 2 with c(v) >= target (1 <= target <= number of q > 1 entries)
+  auto threshold = [&](uint32_t target) -> uint32_t {
+    uint32_t lo = 2u, hi = W;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (countUpTo(mid) >= target) hi = mid;
+      else lo = mid + 1u;
+    }
+    return lo;
+  };
+  while (d > 0u) {
+    const uint32_t n = countUpTo(W);  // entries with q > 1 (q <= W always)
+    if (n == 0u) break;               // cannot happen: the sum would be <= 256 <= W
+    if (d >= n) {
+      // full trips: every q > 1 entry loses 1 per trip until the smallest of them reaches 1
+      // (threshold(1) is the smallest q > 1: one wave minimum instead of a bisection)
+      uint32_t least = 0xffffffffu;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) least = (qq[j] > 1u && qq[j] < least) ? qq[j] : least;
+      const uint32_t m = waveMinDpp(least) - 1u;
+      const uint32_t t = (d / n) < m ? (d / n) : m;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) qq[j] -= (qq[j] > 1u) ? t : 0u;
+      d -= t * n;
+    } else {
+      // last, partial trip: the d smallest keys (q, then symbol) among the q > 1 entries
+      const uint32_t vs = threshold(d);
+      const uint32_t below = vs > 2u ? countUpTo(vs - 1u) : 0u;
+      const uint32_t need = d - below;  // of the entries with q == vs, the first `need` in symbol order
+      uint32_t run = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint64_t m64 = __ballot(qq[j] == vs);
+        run += __builtin_amdgcn_mbcnt_hi((uint32_t)(m64 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m64, 0u));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool eq = qq[j] == vs;
+        const bool dec = (qq[j] > 1u && qq[j] < vs) || (eq && run < need);
+        run += eq ? 1u : 0u;
+        qq[j] -= dec ? 1u : 0u;
+      }
+      d = 0u;
+    }
+  }
+}
+
 // Encoder table entry of one symbol.  The encoder needs q = floor(x / pdf) for states x < 2^31
 // (x >= 16 always): q = umulhi(x, m) >> sh with a 32-bit m, no add-back step
 // (the 33-bit "round-up" magic of the reference, GpuANSStatistics.cuh:349-358, is only needed
@@ -121,6 +193,34 @@ struct NormalizeArgs {
   uint32_t* claims;          // [maxTiles][numInBatch] nullable (encoder's tile claim words)
   uint32_t numInBatch;
 };
+
+// The static part of the ANS archive header of element b (the fields ansEncodeCoalesce writes at
+// GpuANSEncode.cuh:553-566; totalCompressedWords and the reported size are completed by the encode kernel) and, for
+// an EMPTY element -- no encode tile will run for it -- its reported size and float header.  One lane.
+__device__ __forceinline__ void normWriteHeader(const NormalizeArgs& a, uint32_t b, uint32_t total, uint8_t* ans) {
+  const uint32_t nb = divUp(total, kBlockSize);
+  AnsHeader h;
+  h.magicAndVersion = (kAnsMagic << 16) | kAnsVersion;
+  h.numBlocks = nb;
+  h.totalUncompressedWords = total;
+  h.totalCompressedWords = 0;  // completed by k_ans_encode's last tile
+  h.options = (uint32_t)a.probBits | (a.useChecksum ? 0x10u : 0u);
+  h.checksum = (a.useChecksum && a.checksum) ? a.checksum[b] : 0u;
+  h.unused0 = 0;
+  h.unused1 = 0;
+  *(AnsHeader*)ans = h;
+  if (nb == 0) {
+    if (a.outSize) a.outSize[b] = ansOffsetInArchive(a.floatType, total) + ansOverhead(0);
+    if (a.floatType) {
+      FloatHeader fh;
+      fh.magicAndVersion = (kFloatMagic << 16) | kFloatVersion;
+      fh.size = 0;
+      fh.options = a.floatType | (a.floatUseChecksum ? 0x10u : 0u);
+      fh.checksum = 0;
+      *(FloatHeader*)a.out.ptr(b) = fh;
+    }
+  }
+}
 
 // One 256-thread workgroup normalises batch element b.  kCoherent: the partial
 // histograms were written by other workgroups of the SAME kernel (write-through
@@ -211,55 +311,7 @@ __device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const u
       if (wave == 0) {
         const uint4 v4 = ((const uint4*)sKeys)[lane];  // symbols 4 lane .. 4 lane + 3
         uint32_t qq[4] = {v4.x, v4.y, v4.z, v4.w};
-        // c(v) = number of entries with 1 < q <= v  (wave-uniform)
-        auto countUpTo = [&](uint32_t v) -> uint32_t {
-          uint32_t c = 0;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) c += (uint32_t)__popcll(__ballot((qq[j] - 2u) <= (v - 2u)));
-          return c;
-        };
-        // smallest v >= 2 with c(v) >= target (1 <= target <= number of q > 1 entries)
-        auto threshold = [&](uint32_t target) -> uint32_t {
-          uint32_t lo = 2u, hi = W;
-          while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (countUpTo(mid) >= target) hi = mid;
-            else lo = mid + 1u;
-          }
-          return lo;
-        };
-        uint32_t d = (uint32_t)(-diff);
-        while (d > 0u) {
-          const uint32_t n = countUpTo(W);  // entries with q > 1 (q <= W always)
-          if (n == 0u) break;               // cannot happen: the sum would be <= 256 <= W
-          if (d >= n) {
-            // full trips: every q > 1 entry loses 1 per trip until the smallest of them reaches 1
-            const uint32_t m = threshold(1u) - 1u;
-            const uint32_t t = (d / n) < m ? (d / n) : m;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) qq[j] -= (qq[j] > 1u) ? t : 0u;
-            d -= t * n;
-          } else {
-            // last, partial trip: the d smallest keys (q, then symbol) among the q > 1 entries
-            const uint32_t vs = threshold(d);
-            const uint32_t below = vs > 2u ? countUpTo(vs - 1u) : 0u;
-            const uint32_t need = d - below;  // of the entries with q == vs, the first `need` in symbol order
-            uint32_t run = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const uint64_t m64 = __ballot(qq[j] == vs);
-              run += __builtin_amdgcn_mbcnt_hi((uint32_t)(m64 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m64, 0u));
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const bool eq = qq[j] == vs;
-              const bool dec = (qq[j] > 1u && qq[j] < vs) || (eq && run < need);
-              run += eq ? 1u : 0u;
-              qq[j] -= dec ? 1u : 0u;
-            }
-            d = 0u;
-          }
-        }
+        normDeficitTrips(qq, (uint32_t)(-diff), W);
         ((uint4*)sPdf)[lane] = make_uint4(qq[0], qq[1], qq[2], qq[3]);
       }
       __syncthreads();
@@ -292,31 +344,7 @@ __device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const u
 
   if (ans) {
     ((uint16_t*)(ans + sizeof(AnsHeader)))[tid] = (uint16_t)pdf;
-    if (tid == 0) {
-      const uint32_t nb = divUp(total, kBlockSize);
-      AnsHeader h;
-      h.magicAndVersion = (kAnsMagic << 16) | kAnsVersion;
-      h.numBlocks = nb;
-      h.totalUncompressedWords = total;
-      h.totalCompressedWords = 0;  // completed by k_ans_encode's last tile
-      h.options = (uint32_t)P | (a.useChecksum ? 0x10u : 0u);
-      h.checksum = (a.useChecksum && a.checksum) ? a.checksum[b] : 0u;
-      h.unused0 = 0;
-      h.unused1 = 0;
-      *(AnsHeader*)ans = h;
-      if (nb == 0) {
-        // empty element: no encode tile will run for it
-        if (a.outSize) a.outSize[b] = ansOffsetInArchive(a.floatType, total) + ansOverhead(0);
-        if (a.floatType) {
-          FloatHeader fh;
-          fh.magicAndVersion = (kFloatMagic << 16) | kFloatVersion;
-          fh.size = 0;
-          fh.options = a.floatType | (a.floatUseChecksum ? 0x10u : 0u);
-          fh.checksum = 0;
-          *(FloatHeader*)a.out.ptr(b) = fh;
-        }
-      }
-    }
+    if (tid == 0) normWriteHeader(a, b, total, ans);
   }
 }
 

@@ -1137,6 +1137,88 @@ def test_ragged_batches_of_small_elements(dg, prob_bits, blocks):
         assert all((tensor_to_words(ft, o) == w).all() for o, w in zip(outs, ws))
 
 
+def _single_block_count_vectors(rng, trials):
+    """Byte rows of <= 4096 symbols whose histograms drive every branch of the normalisation: a few symbols, all 256,
+    singletons next to one giant (the deficit branch: every count-1 symbol is lifted to probability 1), powers of two,
+    heavy tails; plus an empty row."""
+    rows = []
+    for t in range(trials):
+        k = int(rng.integers(1, 257))
+        syms = rng.choice(256, k, replace=False)
+        mode = t % 6
+        if mode == 0:
+            c = rng.integers(1, 33, k)
+        elif mode == 1:
+            c = np.ones(k, np.int64)
+            c[0] = 4096 - (k - 1)
+        elif mode == 2:
+            c = (rng.pareto(0.7, k) * 3 + 1).astype(np.int64)
+        elif mode == 3:
+            c = 1 << rng.integers(0, 8, k)
+        elif mode == 4:
+            c = np.ones(k, np.int64)
+        else:
+            c = rng.integers(1, 4, k)
+            c[: max(1, k // 16)] = rng.integers(64, 512, max(1, k // 16))
+        c = np.asarray(c, np.int64)
+        while c.sum() > 4096:
+            c = np.maximum(c // 2, 1) if c.max() > 1 else c[:-1]
+        x = np.repeat(syms.astype(np.uint8), c)
+        rng.shuffle(x)
+        rows.append(np.ascontiguousarray(x))
+    rows.append(np.zeros(0, np.uint8))
+    return rows
+
+
+@pytest.mark.parametrize("prob_bits", [9, 10, 11])
+def test_statistics_of_single_block_elements(dg, prob_bits):
+    # batches of single-block elements count and normalise with ONE WAVEFRONT per element (k_stats_single) instead of
+    # a workgroup: whole archives (pdf table, coded words, checksum) against the oracle for histograms that take the
+    # surplus and the deficit branch, as raw bytes and as the compressed byte of the three float types
+    rng = np.random.default_rng(7700 + prob_bits)
+    rows = _single_block_count_vectors(rng, 96)
+    got = gpu_ans_encode(dg, rows, prob_bits, True)
+    for x, g in zip(rows, got):
+        want = O.ans_encode(x, prob_bits, use_checksum=True)
+        assert g.size == want.size and not (g != want).any(), ("raw", x.size, np.unique(x).size)
+    outs, status, osz = gpu_ans_decode(dg, got, [x.size for x in rows], prob_bits, True)
+    assert status.all() and osz.tolist() == [x.size for x in rows] and all((o == x).all() for o, x in zip(outs, rows))
+    for ft in (O.FLOAT16, O.BFLOAT16, O.FLOAT32):
+        ws = []
+        for x in rows:
+            e = x.astype(np.uint32)
+            r = rng.integers(0, 1 << 32, x.size, dtype=np.uint64).astype(np.uint32)
+            if ft == O.FLOAT16:
+                w = ((e << 8) | (r & 0xff)).astype(np.uint16)
+            elif ft == O.BFLOAT16:
+                w = ((e << 7) | (r & 0x7f) | ((r >> 8 & 1) << 15)).astype(np.uint16)
+            else:
+                w = ((e << 23) | (r & 0x7fffff) | ((r >> 24 & 1) << 31)).astype(np.uint32)
+            ws.append(np.ascontiguousarray(w))
+        ts = [words_to_tensor(ft, w) for w in ws]
+        comp, sizes, _ = dg.compress_data(True, ts, True, prob_bits=prob_bits)
+        hs, hc = sizes.cpu().numpy(), comp.cpu().numpy()
+        for i, w in enumerate(ws):
+            want = O.float_compress(ft, w, prob_bits, use_checksum=True)
+            assert hs[i] == want.size and not (hc[i, : hs[i]] != want).any(), (ft, w.size)
+
+
+@pytest.mark.parametrize("prob_bits", [10, 11])
+def test_statistics_of_single_block_elements_at_every_word_alignment(dg, prob_bits):
+    # split-size batches put single-block byte elements at 4-byte (not 16-byte) aligned addresses: the wavefront's
+    # head / vector / tail split of the element (k_stats_single) at all four alignments, ragged sizes
+    rng = np.random.default_rng(7800 + prob_bits)
+    sizes = [4, 1004, 4092, 36, 2052, 4096, 12, 3000, 8, 4088, 20, 100, 4096, 1]
+    xs = [np.ascontiguousarray(refgen.generate_symbols(max(n, 1), 15.0 + 30 * i)[:n], np.uint8) for i, n in enumerate(sizes)]
+    t = to_dev_bytes(np.concatenate(xs))
+    sizes_t = torch.tensor(sizes, dtype=torch.int32)
+    comp_ts, _, _ = dg.compress_data_split_size(False, t, sizes_t, True, prob_bits=prob_bits)
+    for x, c in zip(xs, comp_ts):
+        want = O.ans_encode(x, prob_bits, use_checksum=True)
+        g = c.cpu().numpy()
+        assert g.size == want.size and not (g != want).any(), x.size
+
+
 def test_two_host_threads_on_one_stream(dg):
     # ctypes releases the GIL during a call: two threads enqueue on the SAME stream with no temp memory, i.e. both
     # carve the stream's overflow slab.  Calls serialise on the per-stream lock; every archive must be exact.
