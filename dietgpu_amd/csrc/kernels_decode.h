@@ -323,7 +323,6 @@ __device__ __forceinline__ void decodeBlock(
     uint32_t groups,               // wave-uniform number of 8-row groups to run
     const uint8_t* __restrict__ gwords,  // global: this half's compressed words (16-byte aligned)
     uint32_t numWords,
-    uint8_t* __restrict__ lds,     // LDS base (dynamic LDS starts at offset 0: no static __shared__ here)
     uint32_t ringBase,             // LDS address of this half's 2 KiB ring (multiple of 2048)
     const void* __restrict__ lutRaw, // LDS: uint2 entries, or uint32 entries (kCompact)
     const RowSink<FT>& sink,
@@ -765,7 +764,7 @@ __global__ __launch_bounds__(decThreads(kTileBlocks)) void k_ans_decode(DecodeAr
   const uint32_t xpose = ldsBase + kTileBlocks * kRingBytes + kLutBytesHere + hw * kXpose;
   const uint32_t ringLds = ldsBase + hw * kRingBytes;
 #define DGPU_DECODE_FULL(WIDE, IDLE, NORING) \
-  decodeBlock<P, FT, true, WIDE, IDLE, kCompact, NORING, NORING>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ringLds, sLut, sink, hl, upper, &pre)
+  decodeBlock<P, FT, true, WIDE, IDLE, kCompact, NORING, NORING>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, ringLds, sLut, sink, hl, upper, &pre)
   if (fullPair) {
     if (wide) {
       if (noRing) DGPU_DECODE_FULL(true, false, true); else DGPU_DECODE_FULL(true, false, false);
@@ -781,7 +780,7 @@ __global__ __launch_bounds__(decThreads(kTileBlocks)) void k_ans_decode(DecodeAr
 #undef DGPU_DECODE_FULL
   } else {
     const uint32_t maxN = nFirst > nSecond ? nFirst : nSecond;
-    decodeBlock<P, FT, false, false, false, kCompact>(xpose, state, n, divUp(divUp(maxN, 32u), kGroupRows), gwords, numWords, smem, ringLds, sLut, sink, hl, upper);
+    decodeBlock<P, FT, false, false, false, kCompact>(xpose, state, n, divUp(divUp(maxN, 32u), kGroupRows), gwords, numWords, ringLds, sLut, sink, hl, upper);
   }
 }
 

@@ -50,12 +50,14 @@ __device__ __forceinline__ void pairLdsFence() { asm volatile("s_waitcnt lgkmcnt
 // own 8-slot bins, then lane l folds and normalises symbols 4 l .. 4 l + 3 -- the layout normDeficitTrips works on --
 // and writes the pdf table and the static header fields into the archive (what normalizeElement writes; the encoder
 // table is k_ans_encode_pair's business).  No barriers: the four waves of a workgroup are four elements.
-// Semantics: ansHistogramBatch + ansCalcWeights (GpuANSStatistics.cuh:43-367) per element.
+// Semantics: ansHistogramBatch + ansCalcWeights (GpuANSStatistics.cuh:43-367) per element.  Raw bytes and 16-bit floats
+// (float32 -- half as many symbols per byte of input -- measured slower this way and keeps the workgroup).
 constexpr uint32_t kSingleStatSlots = 8;
 __host__ __device__ constexpr uint32_t statSingleLdsBytes() { return 4u * kNumSymbols * kSingleStatSlots * 4u; }
 
 template <uint32_t FT, bool kNt>
 __global__ __launch_bounds__(256) void k_stats_single(BatchView in, NormalizeArgs a) {
+  static_assert(FT == 0 || FT == kFloat16 || FT == kBFloat16, "float32 batches keep the workgroup per element (capi.hip, encodeCommon)");
   constexpr uint32_t S = kSingleStatSlots;
   __shared__ __attribute__((aligned(16))) uint32_t sBins[4u * kNumSymbols * S];
   const uint32_t lane = threadIdx.x & 63u;
@@ -73,8 +75,6 @@ __global__ __launch_bounds__(256) void k_stats_single(BatchView in, NormalizeArg
   auto addWord = [&](uint32_t x) {  // the symbols of one 32-bit word of input
     if (FT == 0) {
       histAdd4<S>(myBins, x);
-    } else if (FT == kFloat32) {
-      histAdd<S>(myBins, (x >> 23) & 0xffu);
     } else {
       constexpr uint32_t kShift = FT == kFloat16 ? 8u : 7u;
       histAdd<S>(myBins, (x >> kShift) & 0xffu);
@@ -84,35 +84,30 @@ __global__ __launch_bounds__(256) void k_stats_single(BatchView in, NormalizeArg
   auto addOne = [&](uint32_t i) {  // symbol i on its own (heads, tails, unaligned elements)
     uint32_t c;
     if (FT == 0) c = p[i];
-    else if (FT == kFloat32) c = (((const uint32_t*)p)[i] >> 23) & 0xffu;
     else c = ((uint32_t)((const uint16_t*)p)[i] >> (FT == kFloat16 ? 8u : 7u)) & 0xffu;
     histAdd<S>(myBins, c);
   };
-  constexpr uint32_t kSymBytes = FT == 0 ? 1u : (FT == kFloat32 ? 4u : 2u);
+  constexpr uint32_t kSymBytes = FT == 0 ? 1u : 2u;
   constexpr uint32_t kSymPerVec = 16u / kSymBytes;
   // symbols before the first 16-byte boundary (raw bytes come at any alignment; float words that are not aligned to
   // their own size cannot reach a boundary: the whole element then goes symbol by symbol)
   const uint32_t mis = (uint32_t)((uintptr_t)p & 15u);
   uint32_t head = ((16u - mis) & 15u) / kSymBytes;
   if ((mis % kSymBytes) != 0u || head > n) head = n;
-  const uint32_t numVec = (n - head) / kSymPerVec;  // <= 256 (bytes), 512 (16-bit words), 1024 (float32)
+  const uint32_t numVec = (n - head) / kSymPerVec;  // <= 256 (bytes), 512 (16-bit words)
   const uint4* pv = (const uint4*)(p + (size_t)head * kSymBytes);
-  constexpr uint32_t kVecPerLane = 4096u / kSymPerVec / 64u;  // 4 / 8 / 16
-  constexpr uint32_t kBatch = kVecPerLane < 8u ? kVecPerLane : 8u;
+  constexpr uint32_t kVecPerLane = 4096u / kSymPerVec / 64u;  // 4 / 8: all of them in flight at once
   pairLdsFence();  // bins zeroed (this wave's LDS operations execute in order; see pairLdsFence)
+  {
+    uint4 x[kVecPerLane];
 #pragma unroll
-  for (uint32_t k0 = 0; k0 < kVecPerLane; k0 += kBatch) {
-    // a batch of loads in flight, then their symbols
-    uint4 x[kBatch];
-#pragma unroll
-    for (uint32_t k = 0; k < kBatch; ++k) {
-      const uint32_t v = (k0 + k) * 64u + lane;
+    for (uint32_t k = 0; k < kVecPerLane; ++k) {
       x[k] = make_uint4(0, 0, 0, 0);
-      if (v < numVec) x[k] = streamLoad<kNt>(&pv[v]);
+      if (k * 64u + lane < numVec) x[k] = streamLoad<kNt>(&pv[k * 64u + lane]);
     }
 #pragma unroll
-    for (uint32_t k = 0; k < kBatch; ++k) {
-      if ((k0 + k) * 64u + lane < numVec) {
+    for (uint32_t k = 0; k < kVecPerLane; ++k) {
+      if (k * 64u + lane < numVec) {
         addWord(x[k].x);
         addWord(x[k].y);
         addWord(x[k].z);
@@ -512,7 +507,7 @@ __global__ __launch_bounds__(64) void k_ans_decode_pair(DecodeArgs a) {
   pairLdsFence();  // LUTs complete, scratch (= the rings) free
 
 #define DGPU_PAIR_DECODE_FULL(WIDE, NORING) \
-  decodeBlock<P, FT, true, WIDE, false, true, NORING, NORING>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, smem, ringBase, sLut, sink, hl, upper, &pre)
+  decodeBlock<P, FT, true, WIDE, false, true, NORING, NORING>(xpose, state, n, kRowsPerBlock / kGroupRows, gwords, numWords, ringBase, sLut, sink, hl, upper, &pre)
   if (fullBoth) {
     if (wide) {
       if (noRing) DGPU_PAIR_DECODE_FULL(true, true); else DGPU_PAIR_DECODE_FULL(true, false);
@@ -522,7 +517,7 @@ __global__ __launch_bounds__(64) void k_ans_decode_pair(DecodeArgs a) {
 #undef DGPU_PAIR_DECODE_FULL
   } else {
     const uint32_t maxN = nLo > nHi ? nLo : nHi;
-    decodeBlock<P, FT, false, false, false, true>(xpose, state, n, divUp(divUp(maxN, 32u), kGroupRows), gwords, numWords, smem, ringBase, sLut, sink, hl, upper);
+    decodeBlock<P, FT, false, false, false, true>(xpose, state, n, divUp(divUp(maxN, 32u), kGroupRows), gwords, numWords, ringBase, sLut, sink, hl, upper);
   }
 }
 
