@@ -562,7 +562,24 @@ __global__ __launch_bounds__(decThreads(kTileBlocks)) void k_ans_decode(DecodeAr
     }
   }
   const uint8_t* ans = locateAns(archive, FT, &floatSize);
+  // Everything at an offset from the ANS archive that is known NOW is requested in one round trip with the header:
+  // the pdf table (wave 0) and -- float archives: a valid one holds ceil(size / 4096) blocks, which the header check
+  // below confirms -- this half-wave's block descriptor and lane states.  A part is requested early only where it is
+  // known to lie inside the caller's buffer: the caller said how many bytes there are, or (archives of unknown extent)
+  // a checked float header says that an ANS archive of that many blocks follows.  Raw ANS archives learn their block
+  // count from the header and fetch descriptor and states after it, as before.  A load that is not to be made yet
+  // reads the first bytes of the header again.
+  const uint32_t block = tile * kTileBlocks + hw;
+  const bool extentKnown = inBytes != ~0ull;
+  const uint32_t ansOff = ansOffsetInArchive(FT, floatSize);
+  const uint32_t nbSpec = FT ? divUp(floatSize, kBlockSize) : 0u;
+  const bool pdfEarly = extentKnown ? (uint64_t)ansOff + ansOverhead(0u) <= inBytes : FT != 0u;
+  const bool blockEarly = FT != 0u && block < nbSpec && (!extentKnown || (uint64_t)ansOff + ansOverhead(nbSpec) <= inBytes);
   const AnsHeader header = *(const AnsHeader*)ans;
+  uint2 pdfRaw = make_uint2(0u, 0u);
+  if (wave == 0) pdfRaw = *(const uint2*)(pdfEarly ? ans + sizeof(AnsHeader) + 8u * lane : ans);  // pdf[4 lane .. 4 lane + 3]
+  uint2 bwMine = *(const uint2*)(blockEarly ? ans + ansBlockWordsOffset(nbSpec) + 8u * block : ans);
+  uint32_t state = *(const uint32_t*)(blockEarly ? ans + ansStatesOffset() + 4u * (block * 32u + hl) : ans);
   const uint32_t nb = header.numBlocks;
   const uint32_t total = header.totalUncompressedWords;
   const uint32_t totalWords = header.totalCompressedWords;
@@ -607,19 +624,19 @@ __global__ __launch_bounds__(decThreads(kTileBlocks)) void k_ans_decode(DecodeAr
     for (uint32_t i = tid; i < nb; i += kDecThreads) allBlocksOk = allBlocksOk && blockOk(i, blockWords[i]);
   }
 
-  // This half-wave's block descriptor and lane states and (wave 0) the pdf table are requested NOW, in the same round
-  // trip as tile 0's descriptor checks; as soon as the descriptor is there the block's compressed words and its first
-  // non-compressed bytes are requested too (decodePrefetch), and all of it lands while the LUT is being built.
-  const uint32_t block = tile * kTileBlocks + hw;
+  // This half-wave's block descriptor and lane states and (wave 0) the pdf table: already on their way (float
+  // archives, above), or requested NOW, in the same round trip as tile 0's descriptor checks; as soon as the descriptor
+  // is there the block's compressed words and its first non-compressed bytes are requested too (decodePrefetch), and
+  // all of it lands while the LUT is being built.
   bool haveBlock = block < nb;
-  uint2 bwMine = make_uint2(0u, 0u);
-  uint32_t state = 0;
-  if (haveBlock) {
+  if (!haveBlock) {
+    bwMine = make_uint2(0u, 0u);
+    state = 0;
+  } else if (!blockEarly) {  // (for a float archive the checked header has confirmed nb == nbSpec)
     bwMine = blockWords[block];
     state = ((const uint32_t*)(ans + ansStatesOffset()))[block * 32u + hl];  // (inside the archive: nb was checked against inBytes)
   }
-  uint2 pdfRaw = make_uint2(0u, 0u);
-  if (wave == 0) pdfRaw = ((const uint2*)(ans + sizeof(AnsHeader)))[lane];  // pdf[4 lane .. 4 lane + 3]
+  if (wave == 0 && !pdfEarly) pdfRaw = ((const uint2*)(ans + sizeof(AnsHeader)))[lane];
   uint32_t n = 0, numWords = 0, start = 0;
   if (haveBlock) {
     if (blockOk(block, bwMine)) {

@@ -351,34 +351,38 @@ __global__ __launch_bounds__(64) void k_ans_decode_pair(DecodeArgs a) {
   }
   // Everything at a fixed offset from the start of the ANS archive is requested in ONE round trip: the header, the
   // pdf table (8 probabilities per lane) and the descriptor and lane states of the element's block -- a valid archive
-  // of a non-empty element has exactly one block here (capacity <= 4096).  Descriptor and states are requested early
-  // only where they are known to lie inside the caller's buffer: the float header says that the element is not empty,
-  // or the caller said how many bytes there are; otherwise (raw ANS archives of unknown extent) after the header.  A
-  // load that is not to be made yet reads the first bytes of the header again.  (Before: header -> {descriptor, pdf}
-  // -> [LUT build] -> {states, words} = four dependent round trips per element with three wavefronts per SIMD to hide
-  // them.)
+  // of a non-empty element has exactly one block here (capacity <= 4096).  A part is requested early only where it is
+  // known to lie inside the caller's buffer: the caller said how many bytes there are, or (archives of unknown
+  // extent) a checked float header says that an ANS archive follows -- and, for descriptor and states, that the element
+  // is not empty.  Raw ANS archives of unknown extent fetch pdf, descriptor and states after the header was checked,
+  // still in one round trip.  A load that is not to be made yet reads the first bytes of the header again.  (Before:
+  // header -> {descriptor, pdf} -> [LUT build] -> {states, words} = four dependent round trips per element with three
+  // wavefronts per SIMD to hide them.)
   uint2 bw = make_uint2(0u, 0u);
   uint4 rawPdf = make_uint4(0u, 0u, 0u, 0u);
   uint32_t state = 0;
   if (live) {
     const uint32_t ansOff = ansOffsetInArchive(FT, floatSize);
     ans = archive + ansOff;
-    const bool pdfThere = (uint64_t)ansOff + ansOverhead(0u) <= inBytes;
-    const bool early = (uint64_t)ansOff + ansOverhead(1u) <= inBytes && (FT ? floatSize != 0u : inBytes != ~0ull);
+    const bool known = inBytes != ~0ull;
+    const bool pdfEarly = known ? (uint64_t)ansOff + ansOverhead(0u) <= inBytes : FT != 0u;
+    const bool early = known ? (uint64_t)ansOff + ansOverhead(1u) <= inBytes : (FT != 0u && floatSize != 0u);
     const AnsHeader header = *(const AnsHeader*)ans;
-    rawPdf = *(const uint4*)(pdfThere ? ans + sizeof(AnsHeader) + 16u * hl : ans);  // pdf[8 hl .. 8 hl + 7]
+    rawPdf = *(const uint4*)(pdfEarly ? ans + sizeof(AnsHeader) + 16u * hl : ans);  // pdf[8 hl .. 8 hl + 7]
     bw = *(const uint2*)(early ? ans + ansBlockWordsOffset(1u) : ans);
     state = *(const uint32_t*)(early ? ans + ansStatesOffset() + 4u * hl : ans);
     nb = header.numBlocks;
     total = header.totalUncompressedWords;
     totalWords = header.totalCompressedWords;
-    bool success = a.out.size(b) >= total && pdfThere;
+    bool success = a.out.size(b) >= total;
     success = success && header.magicAndVersion == ((kAnsMagic << 16) | kAnsVersion) &&
         (header.options & 0xfu) == (uint32_t)P;
     if (FT) success = success && floatSize == total;
     success = success && nb == divUp(total, kBlockSize);
     success = success && (uint64_t)ansOffsetInArchive(FT, total) + ansOverhead(nb) + 2ull * totalWords <= inBytes;
     if (!success) fail(total);
+    // (a checked header: everything it describes lies inside the archive)
+    if (live && !pdfEarly) rawPdf = ((const uint4*)(ans + sizeof(AnsHeader)))[hl];
     if (live && nb && !early) {
       bw = *(const uint2*)(ans + ansBlockWordsOffset(nb));
       state = ((const uint32_t*)(ans + ansStatesOffset()))[hl];
