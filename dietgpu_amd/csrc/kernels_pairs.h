@@ -484,28 +484,40 @@ __global__ __launch_bounds__(64) void k_ans_decode_pair(DecodeArgs a) {
     }
     pairLdsFence();
     // sym(x) = the largest mark at or below x (cdfs ascend with the symbol; slot 0 belongs to the first present
-    // symbol, so "no mark" = 0 never surfaces); each lane owns 2^P / 32 consecutive slots
-    constexpr uint32_t kEpt = (1u << P) / 32u;
-    uint32_t run[kEpt];
-    {
-      const uint32_t* mw = (const uint32_t*)(sMark + hl * kEpt);
-      uint32_t m = 0;
+    // symbol, so "no mark" = 0 never surfaces).  128 slots per step: a lane owns FOUR consecutive slots of the step --
+    // one dword of marks in, one 16-byte vector of entries out, both at consecutive addresses across the lanes, so
+    // neither conflicts in LDS (a lane owning 2^P / 32 CONSECUTIVE slots wrote its entries at a 32-dword stride: 32
+    // stores per element with all lanes of a half on one bank -- half of the kernel's per-element cost,
+    // profiles/r04_single_block_fixed_cost.txt) -- a max-scan across the half's lanes per step, and the running maximum
+    // of the earlier steps carried along.  The marks live in the tail of the LUT they are replaced by: the entries of
+    // step t overwrite the marks of steps 4 (t - 3 S / 4) .. + 3 <= t (S steps), all read by then.
+    constexpr uint32_t kSteps = (1u << P) / 128u;
+    uint32_t carry = 0;  // largest mark of the earlier steps (uniform per half)
+#pragma unroll 1
+    for (uint32_t t = 0; t < kSteps; ++t) {
+      const uint32_t m4 = ((const uint32_t*)sMark)[t * 32u + hl];
+      uint32_t run[4];
+      run[0] = m4 & 0xffu;
+      run[1] = (m4 >> 8) & 0xffu;
+      run[2] = (m4 >> 16) & 0xffu;
+      run[3] = m4 >> 24;
 #pragma unroll
-      for (uint32_t j = 0; j < kEpt; ++j) {
-        const uint32_t byte = (mw[j / 4u] >> (8u * (j & 3u))) & 0xffu;
-        m = m > byte ? m : byte;
-        run[j] = m;
+      for (int j = 1; j < 4; ++j) run[j] = run[j] > run[j - 1] ? run[j] : run[j - 1];
+      const uint32_t inclMax = halfInclusiveMaxScanDpp(run[3]);
+      uint32_t excl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inclMax, 0x138, 0xf, 0xf, true);  // wave_shr:1
+      if (hl == 0u) excl = 0u;  // (lane 32 would see lane 31's maximum)
+      excl = excl > carry ? excl : carry;
+      uint32_t e[4];
+#pragma unroll
+      for (uint32_t j = 0; j < 4u; ++j) {
+        const uint32_t x = t * 128u + hl * 4u + j;
+        const uint32_t sym = run[j] > excl ? run[j] : excl;
+        e[j] = (sPdf[sym] & 0xfffu) | (((x - sCdf[sym]) & 0xfffu) << 12) | (sym << 24);
       }
-    }
-    const uint32_t inclMax = halfInclusiveMaxScanDpp(run[kEpt - 1u]);
-    uint32_t excl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inclMax, 0x138, 0xf, 0xf, true);  // wave_shr:1
-    if (hl == 0u) excl = 0u;  // (lane 32 would see lane 31's maximum)
-    pairLdsFence();  // every mark is in registers: the LUT may overwrite them
-#pragma unroll
-    for (uint32_t j = 0; j < kEpt; ++j) {
-      const uint32_t x = hl * kEpt + j;
-      const uint32_t sym = run[j] > excl ? run[j] : excl;
-      sLut[x] = (sPdf[sym] & 0xfffu) | (((x - sCdf[sym]) & 0xfffu) << 12) | (sym << 24);
+      const uint32_t last = upper ? (uint32_t)__builtin_amdgcn_readlane((int)inclMax, 63) : (uint32_t)__builtin_amdgcn_readlane((int)inclMax, 31);
+      carry = carry > last ? carry : last;
+      pairLdsFence();  // this step's marks (and the table reads) are in registers: its entries may replace marks
+      ((uint4*)sLut)[t * 32u + hl] = make_uint4(e[0], e[1], e[2], e[3]);
     }
   }
   pairLdsFence();  // LUTs complete, scratch (= the rings) free
