@@ -11,6 +11,7 @@
 #include <atomic>
 #include <climits>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -797,7 +798,7 @@ uint32_t encodeGridPFT(uint32_t tickets) {
   static const uint32_t perCu = [] {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &n, (k_ans_encode<P, FT, encodeSpills(FT), TB>), encThreads(TB), encLdsBytes(P, encodeSpills(FT), FT, TB)) != hipSuccess || n < 1) {
+            &n, (k_ans_encode<P, FT, encodeSpills(FT), TB, true>), encThreads(TB), encLdsBytes(P, encodeSpills(FT), FT, TB)) != hipSuccess || n < 1) {
       n = 1;
     }
     return (uint32_t)n;
@@ -825,23 +826,32 @@ uint32_t encodeGridPF(uint32_t tickets, uint32_t tileBlocks) {
                                           : encodeGridPFT<P, FT, kBlocksPerTile>(tickets);
 }
 
-template <int P, uint32_t FT>
-int launchEncodePF(const EncodeArgs& a, uint32_t tileBlocks, uint32_t grid, hipStream_t stream) {
+template <int P, uint32_t FT, bool kPersistent>
+int launchEncodePFD(const EncodeArgs& a, uint32_t tileBlocks, uint32_t grid, hipStream_t stream) {
   constexpr bool kSpill = encodeSpills(FT);
-  if (tileBlocks == kBlocksPerSingleTile) {
-    DGPU_LAUNCH("k_ans_encode_pair", stream, (k_ans_encode_pair<P, FT, kSpill>), dim3(grid), dim3(64), encPairLdsBytes(P, kSpill, FT), stream, a);
-  } else if (tileBlocks == kBlocksPerTinyTile) {
-    DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT, kSpill, kBlocksPerTinyTile>), dim3(grid), dim3(kBlocksPerTinyTile * 32),
+  if (tileBlocks == kBlocksPerTinyTile) {
+    DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT, kSpill, kBlocksPerTinyTile, kPersistent>), dim3(grid), dim3(kBlocksPerTinyTile * 32),
                 encLdsBytes(P, kSpill, FT, kBlocksPerTinyTile), stream, a);
   } else if (tileBlocks == kBlocksPerSmallTile) {
-    DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT, kSpill, kBlocksPerSmallTile>), dim3(grid), dim3(kBlocksPerSmallTile * 32),
+    DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT, kSpill, kBlocksPerSmallTile, kPersistent>), dim3(grid), dim3(kBlocksPerSmallTile * 32),
                 encLdsBytes(P, kSpill, FT, kBlocksPerSmallTile), stream, a);
   } else {
-    DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT, kSpill, kBlocksPerTile>), dim3(grid), dim3(kBlocksPerTile * 32),
+    DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT, kSpill, kBlocksPerTile, kPersistent>), dim3(grid), dim3(kBlocksPerTile * 32),
                 encLdsBytes(P, kSpill, FT, kBlocksPerTile), stream, a);
   }
   DGPU_HIP(hipGetLastError());
   return DGPU_OK;
+}
+// `hwDispatch`: grid == a.numTickets, one workgroup per tile (k_ans_encode<..., kPersistent = false>)
+template <int P, uint32_t FT>
+int launchEncodePF(const EncodeArgs& a, uint32_t tileBlocks, uint32_t grid, bool hwDispatch, hipStream_t stream) {
+  constexpr bool kSpill = encodeSpills(FT);
+  if (tileBlocks == kBlocksPerSingleTile) {
+    DGPU_LAUNCH("k_ans_encode_pair", stream, (k_ans_encode_pair<P, FT, kSpill>), dim3(grid), dim3(64), encPairLdsBytes(P, kSpill, FT), stream, a);
+    DGPU_HIP(hipGetLastError());
+    return DGPU_OK;
+  }
+  return hwDispatch ? launchEncodePFD<P, FT, false>(a, tileBlocks, grid, stream) : launchEncodePFD<P, FT, true>(a, tileBlocks, grid, stream);
 }
 
 #define DGPU_ENCODE_DISPATCH(P_, FT_, EXPR)                                   \
@@ -874,9 +884,9 @@ uint32_t encodeGrid(int P, uint32_t ft, uint32_t tileBlocks, uint32_t tickets) {
   return g;
 }
 
-int launchEncode(int P, uint32_t ft, const EncodeArgs& a, uint32_t tileBlocks, uint32_t grid, hipStream_t stream) {
+int launchEncode(int P, uint32_t ft, const EncodeArgs& a, uint32_t tileBlocks, uint32_t grid, bool hwDispatch, hipStream_t stream) {
   int rc = DGPU_OK;
-  DGPU_ENCODE_DISPATCH(P, ft, rc = (launchEncodePF<kP, kFT>(a, tileBlocks, grid, stream)));
+  DGPU_ENCODE_DISPATCH(P, ft, rc = (launchEncodePF<kP, kFT>(a, tileBlocks, grid, hwDispatch, stream)));
   return rc;
 }
 
@@ -891,6 +901,20 @@ uint32_t encTileBlocksFor(uint32_t maxSize) {
 uint32_t tilesFor(uint32_t maxSize) { return divUp(divUp(maxSize, kBlockSize), encTileBlocksFor(maxSize)); }
 
 uint32_t absentWorkgroupModulo();  // test hook, defined with the C ABI below
+
+// How the tiled encoder's workgroups come to their tiles: -1 = the library decides, 0 = persistent workgroups with
+// a static ticket map, 1 = one workgroup per tile, dispatched by the hardware (dgpu_debug_set_encoder_dispatch;
+// DGPU_ENC_DISPATCH in the environment sets the initial value, for A/B runs).
+std::atomic<int> g_encDispatch{[] {
+  const char* e = getenv("DGPU_ENC_DISPATCH");
+  return e && *e ? atoi(e) : -1;
+}()};
+bool encoderHardwareDispatch(uint32_t B, uint32_t maxTiles, uint32_t resident, uint32_t floatType) {
+  const int m = g_encDispatch.load();
+  if (m >= 0) return m != 0;
+  (void)B; (void)floatType;
+  return (uint64_t)B * maxTiles > resident;  // more tiles than slots: let the hardware balance them
+}
 
 bool histAccumulates(uint32_t B, uint32_t maxBytes, bool raw) {
   return B <= kHistAccMaxBatch && histPartsAccFor(B, maxBytes) > histPartsFor(B, maxBytes, raw);
@@ -978,6 +1002,29 @@ int encodeCommon(
   DGPU_ALLOC(tileDesc, uint64_t, arena, (size_t)B * std::max(maxTiles, 1u));
   DGPU_ALLOC(claims, uint32_t, arena, (size_t)B * std::max(maxTiles, 1u));
 
+  // The encoder's grid.  `resident` = the workgroups of the kernel that fit on the chip at once.  Tiled kernels are
+  // launched one workgroup per tile (the hardware dispatches them in ticket order as slots free up) or as `resident`
+  // persistent workgroups that walk the tickets with a static map (encoderHardwareDispatch); k_ans_encode_pair is
+  // always persistent.  Spill slots (float inputs): [resident][slots per workgroup]; under hardware dispatch they are
+  // handed out per wavefront through spillFlags.
+  const uint32_t numTickets = B * maxTiles;
+  const uint32_t resident = maxTiles > 0 ? encodeGrid(P, floatType, tileBlocks, numTickets) : 0u;
+  const bool hwDispatch = tileBlocks != kBlocksPerSingleTile && encoderHardwareDispatch(B, maxTiles, resident, floatType);
+  uint16_t* spill = nullptr;
+  uint32_t* spillFlags = nullptr;
+  uint32_t spillPairs = 0;
+  if (maxTiles > 0 && encodeSpills(floatType)) {
+    // (single-block batches: two slots per workgroup, one per element of its pair)
+    const uint32_t slotsPerWg = tileBlocks == kBlocksPerSingleTile ? 2u : tileBlocks;
+    DGPU_ALLOC(sp, uint16_t, arena, (size_t)resident * slotsPerWg * encSpillSlotWords(P));
+    spill = sp;
+    if (hwDispatch) {
+      spillPairs = resident * slotsPerWg / 2u;
+      DGPU_ALLOC(sf, uint32_t, arena, spillPairs);
+      spillFlags = sf;
+    }
+  }
+
   NormalizeArgs n;
   n.sizes = in;
   n.hist = hist_dev;
@@ -998,6 +1045,8 @@ int encodeCommon(
   n.maxTiles = maxTiles;
   n.claims = claims;
   n.numInBatch = B;
+  n.spillFlags = spillFlags;
+  n.spillPairs = spillPairs;
 
   if (!hist_dev && tileBlocks == kBlocksPerSingleTile && maxTiles > 0 && floatType != kFloat32) {
     // batches of single-block elements: one wavefront counts and normalises an element (kernels_pairs.h); no partial
@@ -1072,30 +1121,25 @@ int encodeCommon(
     DGPU_HIP(hipGetLastError());
   }
   if (maxTiles > 0) {
-    const uint32_t grid = encodeGrid(P, floatType, tileBlocks, B * maxTiles);
-    uint16_t* spill = nullptr;
-    if (encodeSpills(floatType)) {
-      // (single-block batches: two slots per workgroup, one per element of its pair)
-      const uint32_t slotsPerWg = tileBlocks == kBlocksPerSingleTile ? 2u : tileBlocks;
-      DGPU_ALLOC(sp, uint16_t, arena, (size_t)grid * slotsPerWg * encSpillSlotWords(P));
-      spill = sp;
-    }
+    const uint32_t grid = hwDispatch ? numTickets : resident;
     EncodeArgs e;
     e.in = in;
     e.out = archives;
     e.encTable = table;
     e.maxTiles = maxTiles;
     e.numInBatch = B;
-    e.numTickets = B * maxTiles;
+    e.numTickets = numTickets;
     e.tileDesc = tileDesc;
     e.claims = claims;
     e.absentModulo = absentWorkgroupModulo();
     e.spill = spill;
+    e.spillFlags = spillFlags;
+    e.spillPairs = spillPairs;
     e.outSize = outSize_dev;
     e.outCapacity = outCapacity;
     e.useChecksum = (useChecksum && floatType) ? 1 : 0;
     e.checksum = (useChecksum && floatType) ? checksumTemp : nullptr;
-    int rc = launchEncode(P, floatType, e, tileBlocks, grid, stream);
+    int rc = launchEncode(P, floatType, e, tileBlocks, grid, hwDispatch, stream);
     if (rc) return rc;
   }
   return DGPU_OK;
@@ -1361,6 +1405,7 @@ uint32_t absentWorkgroupModulo() { return g_absentModulo.load(); }
 }  // namespace
 extern "C" {
 void dgpu_debug_set_absent_workgroups(uint32_t modulo) { g_absentModulo.store(modulo); }
+void dgpu_debug_set_encoder_dispatch(int mode) { g_encDispatch.store(mode < 0 ? -1 : (mode != 0)); }
 void dgpu_debug_set_param_cache(int on) { g_paramCacheEnabled.store(on != 0); }
 void dgpu_set_histogram_load_policy(int mode) { g_histLoadPolicy.store(mode < 0 ? -1 : (mode != 0)); }
 int dgpu_release_graph_state(void) {
@@ -1441,6 +1486,7 @@ static size_t encodeTempBytes(uint32_t B, uint32_t maxBytes, uint32_t wordBytes,
     size_t perCu = (160u * 1024u) / encLdsBytes(9, true, kBFloat16, kBlocksPerTile);
     size_t grid = std::min((size_t)B * tiles, perCu * numComputeUnits());
     t += alignUp(grid * kBlocksPerTile * encSpillSlotWords(11) * 2, kTempAlign);
+    t += alignUp(grid * (kBlocksPerTile / 2) * 4, kTempAlign);  // ... and the flags that hand them out (hardware dispatch)
   }
   return t + kTempAlign;
 }
@@ -1861,6 +1907,8 @@ int dgpu_ans_calc_weights(
   n.tileDesc = nullptr;
   n.maxTiles = 0;
   n.claims = nullptr;
+  n.spillFlags = nullptr;
+  n.spillPairs = 0;
   n.numInBatch = numInBatch;
   hipLaunchKernelGGL(k_normalize, dim3(numInBatch), dim3(256), 0, (hipStream_t)stream, n);
   DGPU_HIP(hipGetLastError());

@@ -309,6 +309,12 @@ int dgpu_prof_summary(char* buf, size_t cap);
  * running workgroups take over the tiles of workgroups that have not started. */
 void dgpu_debug_set_absent_workgroups(uint32_t modulo);
 
+/* Measurement / test hook: how the workgroups of the tiled encoder (k_ans_encode; replaces the grid of
+ * ansEncodeBatch, GpuANSEncode.cuh:429-461) come to their tiles.  -1 (default): the library decides per call;
+ * 0: as many persistent workgroups as fit on the device, static ticket map; 1: one workgroup per tile, dispatched
+ * by the hardware in ticket order.  Archives are byte-identical either way. */
+void dgpu_debug_set_encoder_dispatch(int mode);
+
 /* Measurement hook: 0 makes every pointer-array call upload its parameter block
  * (no reuse of blocks already resident on the device); 1 (default) restores the
  * cache.  bench.py uses it to report the step time without the cache next to the
