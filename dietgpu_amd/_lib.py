@@ -69,6 +69,8 @@ def lib():
             )
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
+            if os.environ.get("DGPU_LIB") and name.startswith("dgpu_debug_") and not hasattr(L, name):
+                continue  # A/B against a library built from an earlier revision (tools/ab.sh): debug hooks may be newer
             fn = getattr(L, name)  # AttributeError if the .so does not export it
             fn.restype = res
             fn.argtypes = args

@@ -795,13 +795,19 @@ constexpr bool encodeSpills(uint32_t ft) { return ft != 0; }
 
 template <int P, uint32_t FT, uint32_t TB>
 uint32_t encodeGridPFT(uint32_t tickets) {
+  // workgroups per CU: the larger of the two variants' (persistent / hardware-dispatched) -- it also sizes the spill
+  // pool, which must have a pair of slots for every wavefront that can be resident
   static const uint32_t perCu = [] {
-    int n = 0;
+    int n = 0, m = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
             &n, (k_ans_encode<P, FT, encodeSpills(FT), TB, true>), encThreads(TB), encLdsBytes(P, encodeSpills(FT), FT, TB)) != hipSuccess || n < 1) {
       n = 1;
     }
-    return (uint32_t)n;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &m, (k_ans_encode<P, FT, encodeSpills(FT), TB, false>), encThreads(TB), encLdsBytes(P, encodeSpills(FT), FT, TB)) != hipSuccess || m < 1) {
+      m = 1;
+    }
+    return (uint32_t)std::max(n, m);
   }();
   return std::max(1u, std::min(tickets, perCu * numComputeUnits()));
 }
@@ -1053,12 +1059,12 @@ int encodeCommon(
     // histograms, no arrival counters.  (Measured on 32768 elements, profiles/r04_ab_single_block_elements.txt:
     // bf16 75.5 -> 65.5 us, fp16 80.5 -> 73.7; float32 -- 16 bytes of input per symbol and lane -- 69 -> 75.5, so
     // float32 keeps the workgroup per element.)
-    const dim3 grid(divUp(B, 4u));
+    const dim3 grid(divUp(B, kSingleStatWaves)), block(64u * kSingleStatWaves);
 #define DGPU_STATS_SINGLE(FT)                                                                                           \
     if (histogramLoadsNonTemporal(floatType)) {                                                                         \
-      DGPU_LAUNCH("k_stats_single", stream, (k_stats_single<FT, true>), grid, dim3(256), 0, stream, in, n);             \
+      DGPU_LAUNCH("k_stats_single", stream, (k_stats_single<FT, true>), grid, block, 0, stream, in, n);                 \
     } else {                                                                                                            \
-      DGPU_LAUNCH("k_stats_single", stream, (k_stats_single<FT, false>), grid, dim3(256), 0, stream, in, n);            \
+      DGPU_LAUNCH("k_stats_single", stream, (k_stats_single<FT, false>), grid, block, 0, stream, in, n);                \
     }
     switch (floatType) {
       case 0: DGPU_STATS_SINGLE(0u) break;

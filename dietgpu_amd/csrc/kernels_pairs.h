@@ -53,16 +53,17 @@ __device__ __forceinline__ void pairLdsFence() { asm volatile("s_waitcnt lgkmcnt
 // Semantics: ansHistogramBatch + ansCalcWeights (GpuANSStatistics.cuh:43-367) per element.  Raw bytes and 16-bit floats
 // (float32 -- half as many symbols per byte of input -- measured slower this way and keeps the workgroup).
 constexpr uint32_t kSingleStatSlots = 8;
-__host__ __device__ constexpr uint32_t statSingleLdsBytes() { return 4u * kNumSymbols * kSingleStatSlots * 4u; }
+constexpr uint32_t kSingleStatWaves = 4;  // elements (= wavefronts) per workgroup
+__host__ __device__ constexpr uint32_t statSingleLdsBytes() { return kSingleStatWaves * kNumSymbols * kSingleStatSlots * 4u; }
 
 template <uint32_t FT, bool kNt>
-__global__ __launch_bounds__(256) void k_stats_single(BatchView in, NormalizeArgs a) {
+__global__ __launch_bounds__(64 * kSingleStatWaves) void k_stats_single(BatchView in, NormalizeArgs a) {
   static_assert(FT == 0 || FT == kFloat16 || FT == kBFloat16, "float32 batches keep the workgroup per element (capi.hip, encodeCommon)");
   constexpr uint32_t S = kSingleStatSlots;
-  __shared__ __attribute__((aligned(16))) uint32_t sBins[4u * kNumSymbols * S];
+  __shared__ __attribute__((aligned(16))) uint32_t sBins[kSingleStatWaves * kNumSymbols * S];
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
-  const uint32_t b = blockIdx.x * 4u + wave;
+  const uint32_t b = blockIdx.x * kSingleStatWaves + wave;
   if (b >= a.numInBatch) return;  // wave-uniform; no barriers in this kernel
 
   uint32_t* bins = sBins + wave * kNumSymbols * S;

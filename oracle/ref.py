@@ -35,6 +35,19 @@ def build(force=False):
     return LIB
 
 
+def stage_python_tests():
+    """Stages the reference's own Python tests (dietgpu/ans_test.py, float_test.py) in oracle/_ref/ next to the library
+    built from its sources: same category (reference-derived TEST artefact, git-ignored, never committed), same reason
+    (the GPU box has no /root/reference; oracle/_ref/ travels there).  tests/test_reference_python_tests.py runs them."""
+    import shutil
+
+    dst = os.path.join(os.path.dirname(LIB), "reference_python_tests")
+    os.makedirs(dst, exist_ok=True)
+    for name in ("ans_test.py", "float_test.py"):
+        shutil.copyfile(os.path.join(REFERENCE_ROOT, "dietgpu", name), os.path.join(dst, name))
+    return dst
+
+
 def available():
     return os.path.exists(LIB)
 

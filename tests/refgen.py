@@ -49,9 +49,16 @@ def generate_floats(ft, num):
 def zipf_bytes(batch, n, s=1.2, seed=1234):
     p = 1.0 / (np.arange(256) + 1.0) ** s
     p /= p.sum()
-    return np.stack(
-        [np.random.default_rng(seed + b).choice(256, size=n, p=p).astype(np.uint8) for b in range(batch)]
-    )
+
+    def row(b):  # every row is its own stream: rows can be drawn concurrently
+        return np.random.default_rng(seed + b).choice(256, size=n, p=p).astype(np.uint8)
+
+    if batch * n >= (1 << 24):
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as ex:  # (numpy releases the GIL in choice / searchsorted)
+            return np.stack(list(ex.map(row, range(batch))))
+    return np.stack([row(b) for b in range(batch)])
 
 
 def f32_to_bf16_rne(f):

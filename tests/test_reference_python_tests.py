@@ -2,11 +2,13 @@
 
 `dietgpu/ans_test.py` and `dietgpu/float_test.py` of a facebookresearch/dietgpu checkout are run unmodified with
 `torch.ops.load_library` pointed at this repository's libdietgpu_torch.so (their only tie to the reference's build is
-the line `torch.ops.load_library("//dietgpu:dietgpu")`).  They need a GPU AND a checkout: /root/reference, or
-$DIETGPU_REFERENCE_ROOT.  The build container has the checkout and no GPU, the GPU boxes of this project have a GPU
-and no checkout (reference sources may not be copied into this repository), so in this project's own runs the test
-skips in both places -- tests/test_torch_ops.py is the restatement that does run; this file is what a maintainer with
-both at hand runs (`python tools/run_reference_python_tests.py <checkout>` does the same outside pytest)."""
+the line `torch.ops.load_library("//dietgpu:dietgpu")`).  They need a GPU AND the two files: from a checkout
+(/root/reference, or $DIETGPU_REFERENCE_ROOT), or -- the GPU boxes of this project have no checkout -- from
+oracle/_ref/reference_python_tests/, where `__graft_entry__.build()` stages them in the build container next to
+libdietgpu_ref.so.  oracle/_ref/ is git-ignored (reference-derived test artefacts are never committed) but travels to
+the GPU box with the built libraries.  Without a GPU the tests skip; tests/test_torch_ops.py is the restatement that
+covers the same calls with the oracle as the judge.  `python tools/run_reference_python_tests.py <checkout>` does the
+same outside pytest."""
 import os
 import runpy
 import sys
@@ -17,11 +19,25 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.environ.get("DIETGPU_REFERENCE_ROOT", "/root/reference")
-FILES = [os.path.join(REF, "dietgpu", f) for f in ("ans_test.py", "float_test.py")]
+STAGED = os.path.join(ROOT, "oracle", "_ref", "reference_python_tests")
+NAMES = ("ans_test.py", "float_test.py")
+
+
+def _files():
+    for d in (os.path.join(REF, "dietgpu"), STAGED):
+        fs = [os.path.join(d, f) for f in NAMES]
+        if all(os.path.exists(f) for f in fs):
+            return fs
+    return [os.path.join(STAGED, f) for f in NAMES]
+
+
+FILES = _files()
 
 pytestmark = [
     pytest.mark.gpu,
-    pytest.mark.skipif(not all(os.path.exists(f) for f in FILES), reason=f"no facebookresearch/dietgpu checkout at {REF}"),
+    pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU"),
+    pytest.mark.skipif(not all(os.path.exists(f) for f in FILES),
+                       reason=f"neither a facebookresearch/dietgpu checkout at {REF} nor staged copies in {STAGED}"),
 ]
 
 
