@@ -13,6 +13,7 @@ _lib = None
 u32, i32, sz, vp = C.c_uint32, C.c_int, C.c_size_t, C.c_void_p
 _SIGS = {
     "dgpu_version": (C.c_char_p, []),
+    "dgpu_abi_version": (u32, []),
     "dgpu_last_error": (C.c_char_p, []),
     "dgpu_last_checksum_mismatches": (C.c_uint32, [C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32]),
     "dgpu_ans_max_compressed_size": (u32, [u32]),
@@ -69,8 +70,8 @@ def lib():
             )
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
-            if os.environ.get("DGPU_LIB") and name.startswith("dgpu_debug_") and not hasattr(L, name):
-                continue  # A/B against a library built from an earlier revision (tools/ab.sh): debug hooks may be newer
+            if os.environ.get("DGPU_LIB") and not hasattr(L, name):
+                continue  # A/B against a library built from an earlier revision (tools/ab.sh): entry points may be newer
             fn = getattr(L, name)  # AttributeError if the .so does not export it
             fn.restype = res
             fn.argtypes = args

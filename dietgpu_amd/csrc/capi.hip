@@ -141,6 +141,10 @@ struct StreamState {
   uint8_t* slab = nullptr;
   size_t slabCap = 0;
   std::vector<void*> retired;
+  // slabs a CAPTURED call carved memory from: a HIP graph replays into them, so they outlive their retirement (until
+  // dgpu_release_graph_state); slabInGraph: the current slab is such a slab
+  bool slabInGraph = false;
+  std::vector<void*> graphSlabs;
   // 65536 arrival counters + kAccElements x 256 histogram counters (zero at rest)
   uint32_t* counters = nullptr;
   // a call was CAPTURED into a HIP graph with pointers into this state (slab, counters): the graph replays without
@@ -150,6 +154,9 @@ struct StreamState {
   void releaseDeviceMemory() {
     for (void* p : retired) (void)hipFree(p);
     retired.clear();
+    for (void* p : graphSlabs) (void)hipFree(p);
+    graphSlabs.clear();
+    slabInGraph = false;
     if (slab) (void)hipFree(slab);
     if (counters) (void)hipFree(counters);
     slab = nullptr;
@@ -229,6 +236,7 @@ class StreamRegistry {
         s->slab = nullptr;  // cannot prove idleness: leak rather than free under running kernels
         s->counters = nullptr;
         s->retired.clear();
+        s->graphSlabs.clear();
       }
       s->busy.unlock();
       delete s;
@@ -352,11 +360,9 @@ class TempArena {
       overflowUsed_ = true;
       // first overflow allocation of this call: slabs retired by EARLIER calls can go
       // (their kernels precede everything this call enqueues on the stream) -- not while the stream is being
-      // captured: a synchronise would invalidate the capture, they wait for the next plain call -- and NEVER once a
-      // call on this stream was captured into a HIP graph: the graph replays with the address of the slab that was
-      // current at capture time, which a later, larger call may have retired.  Those slabs stay until
-      // dgpu_release_graph_state() (the promise of include/dietgpu_amd.h: "neither evicted nor trimmed nor released").
-      if (!s->retired.empty() && !lease_.capturing() && !s->graphPinned) {
+      // captured: a synchronise would invalidate the capture, they wait for the next plain call.  Slabs that a
+      // captured call carved memory from are not in this list: a graph replays with their address (graphSlabs).
+      if (!s->retired.empty() && !lease_.capturing()) {
         *err = hipStreamSynchronize(lease_.stream());
         if (*err != hipSuccess) return nullptr;
         for (void* p : s->retired) (void)hipFree(p);
@@ -375,12 +381,15 @@ class TempArena {
       void* p = nullptr;
       *err = hipMalloc(&p, cap);
       if (*err != hipSuccess) return nullptr;
-      // the old slab may hold allocations of THIS call: retire it, never free it here
-      if (s->slab) s->retired.push_back(s->slab);
+      // the old slab may hold allocations of THIS call: retire it, never free it here; one that a HIP graph replays
+      // into stays until dgpu_release_graph_state() ("neither evicted nor trimmed nor released", dietgpu_amd.h)
+      if (s->slab) (s->slabInGraph ? s->graphSlabs : s->retired).push_back(s->slab);
+      s->slabInGraph = false;
       s->slab = (uint8_t*)p;
       s->slabCap = cap;
       overflowHead_ = 0;
     }
+    if (lease_.capturing()) s->slabInGraph = true;
     void* out = s->slab + overflowHead_;
     overflowHead_ += need;
     return out;
@@ -1392,6 +1401,7 @@ int splitSizesToPointers(
 extern "C" {
 
 const char* dgpu_version(void) { return "dietgpu_amd 0.1 (gfx950)"; }
+uint32_t dgpu_abi_version(void) { return DGPU_ABI_VERSION; }
 const char* dgpu_last_error(void) { return g_lastError.c_str(); }
 
 uint32_t dgpu_last_checksum_mismatches(int32_t* batchIdx, uint32_t* expected, uint32_t* got, uint32_t cap) {

@@ -464,6 +464,10 @@ TORCH_LIBRARY_FRAGMENT(dietgpu, m) {
 }
 
 TORCH_LIBRARY(dietgpu, m) {
+  // a libdietgpu_amd.so from another build of the sources than this file was compiled against: fail at load
+  TORCH_CHECK(dgpu_abi_version() == DGPU_ABI_VERSION, "libdietgpu_torch.so was built against C ABI version ",
+              DGPU_ABI_VERSION, " of dietgpu_amd.h, the libdietgpu_amd.so it found has version ", dgpu_abi_version(),
+              ": rebuild (python -m dietgpu_amd.build)");
   m.impl(TORCH_SELECTIVE_NAME("dietgpu::max_float_compressed_output_size"), TORCH_FN(dietgpu_amd::max_float_compressed_output_size));
   m.impl(TORCH_SELECTIVE_NAME("dietgpu::max_float_compressed_size"), TORCH_FN(dietgpu_amd::max_float_compressed_size));
   m.impl(TORCH_SELECTIVE_NAME("dietgpu::max_any_compressed_output_size"), TORCH_FN(dietgpu_amd::max_any_compressed_output_size));

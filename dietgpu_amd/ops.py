@@ -19,6 +19,7 @@ on both routes).  Either way the work is done by libdietgpu_amd.so: there is no 
 """
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -32,7 +33,8 @@ _U32_MAX = (1 << 32) - 1
 
 
 _PREFER_TORCH_OPS = True
-_TORCH_OPS = None  # None: not tried yet; False: libdietgpu_torch.so is not there
+_TORCH_OPS = None  # None: not tried yet; False: libdietgpu_torch.so is not there (or stale)
+_TORCH_OPS_LOCK = threading.Lock()
 
 
 def prefer_torch_ops(enable=True):
@@ -46,15 +48,33 @@ def _fast_ops(prob_bits):
     if prob_bits != K_DEFAULT_PRECISION or not _PREFER_TORCH_OPS:
         return None
     if _TORCH_OPS is None:
-        from .build import TORCH_LIB_PATH
-
-        if os.path.exists(TORCH_LIB_PATH):
-            lib()  # libdietgpu_amd.so first (the op library links against it)
-            torch.ops.load_library(TORCH_LIB_PATH)
-            _TORCH_OPS = torch.ops.dietgpu
-        else:
-            _TORCH_OPS = False
+        with _TORCH_OPS_LOCK:
+            if _TORCH_OPS is None:
+                _TORCH_OPS = _load_fast_ops()
     return _TORCH_OPS or None
+
+
+def _load_fast_ops():
+    """torch.ops.dietgpu from the in-tree op library, or False.  An op library that is OLDER than the core library it
+    links against was built from other sources (dietgpu_amd.build rebuilds both together): it is not loaded -- the
+    ctypes route serves the call -- and the op library itself refuses to load against another DGPU_ABI_VERSION."""
+    import warnings
+
+    from .build import LIB_PATH, TORCH_LIB_PATH
+
+    if not os.path.exists(TORCH_LIB_PATH):
+        return False
+    if os.path.getmtime(TORCH_LIB_PATH) < os.path.getmtime(LIB_PATH) and not os.environ.get("DGPU_LIB"):
+        warnings.warn(f"{TORCH_LIB_PATH} is older than {LIB_PATH}: not loaded, the ctypes route is used "
+                      "(python -m dietgpu_amd.build rebuilds both)")
+        return False
+    lib()  # libdietgpu_amd.so first (the op library links against it)
+    try:
+        torch.ops.load_library(TORCH_LIB_PATH)
+    except (OSError, RuntimeError) as e:
+        warnings.warn(f"{TORCH_LIB_PATH} could not be loaded ({e}): the ctypes route is used")
+        return False
+    return torch.ops.dietgpu
 
 
 def _check(cond, msg="argument check failed"):

@@ -61,6 +61,11 @@ extern "C" {
 #define DGPU_ANS_DEFAULT_PROB_BITS 10
 
 const char* dgpu_version(void);
+/* Bumped whenever an entry point of this header is added, removed or changes its meaning.  Code that is built
+ * separately against this header (csrc/torch_ops.cpp, a cgo / JNI binding) compares the value it was compiled with
+ * against the library it finds at run time, so that a stale build fails at load instead of inside a call. */
+#define DGPU_ABI_VERSION 5u
+uint32_t dgpu_abi_version(void);
 /* Text of the last error on the calling thread (HIP error string, failed
  * precondition).  The reference aborts through glog CHECK instead. */
 const char* dgpu_last_error(void);
@@ -121,6 +126,14 @@ int dgpu_ans_encode_batch_split_size(
     void* stream);
 
 /* ---- rANS decode --------------------------------------------------------- */
+/* What the entry points WITHOUT input sizes may read (the reference's contract, made explicit): up to
+ * dgpu_ans_max_compressed_size(outCapacity) / dgpu_float_max_compressed_size(type, outCapacity) bytes from every input
+ * pointer -- the size of the buffer an encoder was given for an element of that capacity (GpuANSCodec.h:24-26,
+ * GpuFloatCodec.h:54-57).  Inside that extent every format invariant is checked before it is followed; the decoders
+ * request the probability table and (float archives, once the float header has been checked) the block descriptor
+ * and lane states of the blocks the header implies in the same round trip as the ANS header, i.e. before that header
+ * has been validated.  Callers that hold archives in buffers SMALLER than that -- received, truncated to their size --
+ * use the *_bounded entry points below, which read nothing beyond the bytes they are told exist. */
 /* ansDecodeBatchStride, GpuANSCodec.h:170-226 / GpuANSDecode.cu:20-45 */
 int dgpu_ans_decode_batch_stride(
     void* temp_dev, size_t tempBytes, size_t* tempUsed,

@@ -634,7 +634,16 @@ typedef struct {
   uint8_t* comp; size_t compStride; uint8_t* out; size_t rowBytes;
   int tid, nthreads, reps, pin;
   pthread_barrier_t* bar; double* encSeconds; double* decSeconds; int* bad;
+  struct bench_gate* gate;
 } bench_t;
+
+/* start gate: the workers touch the barrier only once EVERY thread exists (a barrier sized for `threads` never fills
+ * when pthread_create fails midway; the threads already started are then told to leave instead) */
+struct bench_gate {
+  pthread_mutex_t mu;
+  pthread_cond_t cv;
+  int state; /* 0: wait, 1: go, 2: abort */
+};
 
 static double now_s(void) {
   struct timespec ts;
@@ -644,6 +653,11 @@ static double now_s(void) {
 
 static void* bench_worker(void* p) {
   bench_t* j = (bench_t*)p;
+  pthread_mutex_lock(&j->gate->mu);
+  while (j->gate->state == 0) pthread_cond_wait(&j->gate->cv, &j->gate->mu);
+  const int go = j->gate->state == 1;
+  pthread_mutex_unlock(&j->gate->mu);
+  if (!go) return NULL;
   if (j->pin) {
     /* the tid-th CPU of the set this process may run on */
     cpu_set_t allowed, one;
@@ -707,11 +721,17 @@ int dgo_bench_roundtrip(
   pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
   bench_t* jobs = (bench_t*)malloc(sizeof(bench_t) * (size_t)threads);
   pthread_barrier_t bar;
+  struct bench_gate gate;
   int bad = 0, rc = 0;
   if (!comp || !out || !th || !jobs || pthread_barrier_init(&bar, NULL, (unsigned)threads) != 0) {
     free(comp); free(out); free(th); free(jobs);
+    mallopt(M_MMAP_THRESHOLD, 128 * 1024);
+    mallopt(M_TRIM_THRESHOLD, 128 * 1024);
     return -1;
   }
+  pthread_mutex_init(&gate.mu, NULL);
+  pthread_cond_init(&gate.cv, NULL);
+  gate.state = 0;
   int started = 0;
   for (int t = 0; t < threads; ++t) {
     bench_t j;
@@ -719,18 +739,23 @@ int dgo_bench_roundtrip(
     j.ft = ft; j.in = (const uint8_t*)in; j.inStride = inStride; j.size = size; j.batch = batch; j.probBits = probBits;
     j.comp = comp; j.compStride = compStride; j.out = out; j.rowBytes = rowBytes;
     j.tid = t; j.nthreads = threads; j.reps = reps; j.pin = pin;
-    j.bar = &bar; j.encSeconds = encSeconds; j.decSeconds = decSeconds; j.bad = &bad;
+    j.bar = &bar; j.encSeconds = encSeconds; j.decSeconds = decSeconds; j.bad = &bad; j.gate = &gate;
     jobs[t] = j;
     if (pthread_create(&th[t], NULL, bench_worker, &jobs[t]) != 0) { rc = -1; break; }
     ++started;
   }
-  if (rc != 0) {
-    /* cannot release threads parked on a barrier that will never fill: leave them (test infrastructure) */
-    return -1;
-  }
+  pthread_mutex_lock(&gate.mu);
+  gate.state = rc == 0 ? 1 : 2; /* all threads exist: go; otherwise the started ones leave without touching the barrier */
+  pthread_cond_broadcast(&gate.cv);
+  pthread_mutex_unlock(&gate.mu);
   for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
   pthread_barrier_destroy(&bar);
+  pthread_cond_destroy(&gate.cv);
+  pthread_mutex_destroy(&gate.mu);
   if (mismatches) *mismatches = bad;
   free(comp); free(out); free(th); free(jobs);
-  return 0;
+  /* back to glibc's documented defaults: this is somebody's Python process, not ours */
+  mallopt(M_MMAP_THRESHOLD, 128 * 1024);
+  mallopt(M_TRIM_THRESHOLD, 128 * 1024);
+  return rc;
 }

@@ -56,3 +56,35 @@ def test_collection_from_the_repo_root_needs_no_gpu():
     assert "error" not in p.stdout.lower().split("\n")[-2], p.stdout[-500:]
     # and nothing under tools/ (experiment scripts that do GPU work at import) is collected
     assert "tools/" not in p.stdout
+
+
+def test_abi_version_of_the_library_is_the_headers():
+    # what csrc/torch_ops.cpp checks at load and dietgpu_amd.ops before it hands calls to the op library
+    import re
+
+    import dietgpu_amd
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "include", "dietgpu_amd.h")) as f:
+        want = int(re.search(r"#define DGPU_ABI_VERSION (\d+)u", f.read()).group(1))
+    assert dietgpu_amd.lib().dgpu_abi_version() == want
+
+
+def test_stale_op_library_is_not_loaded(tmp_path, monkeypatch):
+    # an op library older than the core library was built from other sources: dietgpu_amd.ops keeps to the ctypes route
+    import warnings
+
+    from dietgpu_amd import build, ops
+
+    core = tmp_path / "libdietgpu_amd.so"
+    stale = tmp_path / "libdietgpu_torch.so"
+    stale.write_bytes(b"")
+    core.write_bytes(b"")
+    os.utime(stale, (1, 1))
+    monkeypatch.setattr(build, "LIB_PATH", str(core))
+    monkeypatch.setattr(build, "TORCH_LIB_PATH", str(stale))
+    monkeypatch.delenv("DGPU_LIB", raising=False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert ops._load_fast_ops() is False
+    assert any("older than" in str(x.message) for x in w)
