@@ -804,19 +804,13 @@ constexpr bool encodeSpills(uint32_t ft) { return ft != 0; }
 
 template <int P, uint32_t FT, uint32_t TB>
 uint32_t encodeGridPFT(uint32_t tickets) {
-  // workgroups per CU: the larger of the two variants' (persistent / hardware-dispatched) -- it also sizes the spill
-  // pool, which must have a pair of slots for every wavefront that can be resident
   static const uint32_t perCu = [] {
-    int n = 0, m = 0;
+    int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
             &n, (k_ans_encode<P, FT, encodeSpills(FT), TB, true>), encThreads(TB), encLdsBytes(P, encodeSpills(FT), FT, TB)) != hipSuccess || n < 1) {
       n = 1;
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &m, (k_ans_encode<P, FT, encodeSpills(FT), TB, false>), encThreads(TB), encLdsBytes(P, encodeSpills(FT), FT, TB)) != hipSuccess || m < 1) {
-      m = 1;
-    }
-    return (uint32_t)std::max(n, m);
+    return (uint32_t)n;
   }();
   return std::max(1u, std::min(tickets, perCu * numComputeUnits()));
 }
@@ -866,7 +860,10 @@ int launchEncodePF(const EncodeArgs& a, uint32_t tileBlocks, uint32_t grid, bool
     DGPU_HIP(hipGetLastError());
     return DGPU_OK;
   }
-  return hwDispatch ? launchEncodePFD<P, FT, false>(a, tileBlocks, grid, stream) : launchEncodePFD<P, FT, true>(a, tileBlocks, grid, stream);
+  if constexpr (!kSpill) {
+    if (hwDispatch) return launchEncodePFD<P, FT, false>(a, tileBlocks, grid, stream);
+  }
+  return launchEncodePFD<P, FT, true>(a, tileBlocks, grid, stream);
 }
 
 #define DGPU_ENCODE_DISPATCH(P_, FT_, EXPR)                                   \
@@ -917,18 +914,23 @@ uint32_t tilesFor(uint32_t maxSize) { return divUp(divUp(maxSize, kBlockSize), e
 
 uint32_t absentWorkgroupModulo();  // test hook, defined with the C ABI below
 
-// How the tiled encoder's workgroups come to their tiles: -1 = the library decides, 0 = persistent workgroups with
-// a static ticket map, 1 = one workgroup per tile, dispatched by the hardware (dgpu_debug_set_encoder_dispatch;
-// DGPU_ENC_DISPATCH in the environment sets the initial value, for A/B runs).
+// How the workgroups of the tiled RAW-BYTE encoder come to their tiles: -1 = the library decides, 0 = persistent
+// workgroups with a static ticket map, 1 = one workgroup per tile, dispatched by the hardware
+// (dgpu_debug_set_encoder_dispatch; DGPU_ENC_DISPATCH in the environment sets the initial value, for A/B runs).
+// Measured on MI355X (profiles/r05_ab_encoder_hw_dispatch.txt): 256 x 1 MiB Zipf bytes 152.7 -> 141.5 us -- 8192 tiles
+// on 768 resident workgroups (3 per CU) are 10.67 rounds, and the compute-bound row loop of a slow CU no longer holds
+// a fixed share of them.  The float encoders (6 workgroups per CU, memory-bound) gain nothing on 256 x 512 Ki and lose
+// 1-3 % on few large tensors, and a hardware-dispatched grid has no natural owner for their spill slots: they stay
+// persistent (the variant with a spill-slot pool: tools/experiments/encoder_hardware_dispatch_for_floats.patch).
 std::atomic<int> g_encDispatch{[] {
   const char* e = getenv("DGPU_ENC_DISPATCH");
   return e && *e ? atoi(e) : -1;
 }()};
-bool encoderHardwareDispatch(uint32_t B, uint32_t maxTiles, uint32_t resident, uint32_t floatType) {
+bool encoderHardwareDispatch(uint32_t numTickets, uint32_t resident, uint32_t floatType) {
+  if (encodeSpills(floatType)) return false;
   const int m = g_encDispatch.load();
   if (m >= 0) return m != 0;
-  (void)B; (void)floatType;
-  return (uint64_t)B * maxTiles > resident;  // more tiles than slots: let the hardware balance them
+  return numTickets > resident;  // more tiles than slots: let the hardware balance them
 }
 
 bool histAccumulates(uint32_t B, uint32_t maxBytes, bool raw) {
@@ -1017,27 +1019,19 @@ int encodeCommon(
   DGPU_ALLOC(tileDesc, uint64_t, arena, (size_t)B * std::max(maxTiles, 1u));
   DGPU_ALLOC(claims, uint32_t, arena, (size_t)B * std::max(maxTiles, 1u));
 
-  // The encoder's grid.  `resident` = the workgroups of the kernel that fit on the chip at once.  Tiled kernels are
-  // launched one workgroup per tile (the hardware dispatches them in ticket order as slots free up) or as `resident`
-  // persistent workgroups that walk the tickets with a static map (encoderHardwareDispatch); k_ans_encode_pair is
-  // always persistent.  Spill slots (float inputs): [resident][slots per workgroup]; under hardware dispatch they are
-  // handed out per wavefront through spillFlags.
+  // The encoder's grid.  `resident` = the workgroups of the kernel that fit on the chip at once.  The tiled kernels run
+  // as `resident` persistent workgroups that walk the tickets with a static map, or -- raw bytes, when there are more
+  // tiles than that -- as one workgroup per tile, dispatched by the hardware in ticket order (encoderHardwareDispatch);
+  // k_ans_encode_pair is always persistent.  Spill slots (float inputs, persistent): [resident][slots per workgroup].
   const uint32_t numTickets = B * maxTiles;
   const uint32_t resident = maxTiles > 0 ? encodeGrid(P, floatType, tileBlocks, numTickets) : 0u;
-  const bool hwDispatch = tileBlocks != kBlocksPerSingleTile && encoderHardwareDispatch(B, maxTiles, resident, floatType);
+  const bool hwDispatch = tileBlocks != kBlocksPerSingleTile && encoderHardwareDispatch(numTickets, resident, floatType);
   uint16_t* spill = nullptr;
-  uint32_t* spillFlags = nullptr;
-  uint32_t spillPairs = 0;
   if (maxTiles > 0 && encodeSpills(floatType)) {
     // (single-block batches: two slots per workgroup, one per element of its pair)
     const uint32_t slotsPerWg = tileBlocks == kBlocksPerSingleTile ? 2u : tileBlocks;
     DGPU_ALLOC(sp, uint16_t, arena, (size_t)resident * slotsPerWg * encSpillSlotWords(P));
     spill = sp;
-    if (hwDispatch) {
-      spillPairs = resident * slotsPerWg / 2u;
-      DGPU_ALLOC(sf, uint32_t, arena, spillPairs);
-      spillFlags = sf;
-    }
   }
 
   NormalizeArgs n;
@@ -1060,8 +1054,6 @@ int encodeCommon(
   n.maxTiles = maxTiles;
   n.claims = claims;
   n.numInBatch = B;
-  n.spillFlags = spillFlags;
-  n.spillPairs = spillPairs;
 
   if (!hist_dev && tileBlocks == kBlocksPerSingleTile && maxTiles > 0 && floatType != kFloat32) {
     // batches of single-block elements: one wavefront counts and normalises an element (kernels_pairs.h); no partial
@@ -1148,8 +1140,6 @@ int encodeCommon(
     e.claims = claims;
     e.absentModulo = absentWorkgroupModulo();
     e.spill = spill;
-    e.spillFlags = spillFlags;
-    e.spillPairs = spillPairs;
     e.outSize = outSize_dev;
     e.outCapacity = outCapacity;
     e.useChecksum = (useChecksum && floatType) ? 1 : 0;
@@ -1502,7 +1492,6 @@ static size_t encodeTempBytes(uint32_t B, uint32_t maxBytes, uint32_t wordBytes,
     size_t perCu = (160u * 1024u) / encLdsBytes(9, true, kBFloat16, kBlocksPerTile);
     size_t grid = std::min((size_t)B * tiles, perCu * numComputeUnits());
     t += alignUp(grid * kBlocksPerTile * encSpillSlotWords(11) * 2, kTempAlign);
-    t += alignUp(grid * (kBlocksPerTile / 2) * 4, kTempAlign);  // ... and the flags that hand them out (hardware dispatch)
   }
   return t + kTempAlign;
 }
@@ -1923,8 +1912,6 @@ int dgpu_ans_calc_weights(
   n.tileDesc = nullptr;
   n.maxTiles = 0;
   n.claims = nullptr;
-  n.spillFlags = nullptr;
-  n.spillPairs = 0;
   n.numInBatch = numInBatch;
   hipLaunchKernelGGL(k_normalize, dim3(numInBatch), dim3(256), 0, (hipStream_t)stream, n);
   DGPU_HIP(hipGetLastError());

@@ -726,37 +726,59 @@ __global__ __launch_bounds__(decThreads(kTileBlocks)) void k_ans_decode(DecodeAr
         if (sPdf[sidx]) sMark[sCdf[sidx]] = (uint8_t)sidx;
       }
       __syncthreads();
-      constexpr uint32_t kEpt = (1u << P) / kDecThreads;  // slots per thread: 4 / 8 / 16
-      uint32_t run[kEpt];
-      {
-        const uint32_t* mw = (const uint32_t*)(sMark + tid * kEpt);
-        uint32_t m = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < kEpt; ++j) {
-          const uint32_t byte = (mw[j / 4u] >> (8u * (j & 3u))) & 0xffu;
-          m = m > byte ? m : byte;
-          run[j] = m;
-        }
-      }
-      // inclusive max-scan of the per-thread maxima across the wave (DPP), then across the waves
-      uint32_t incl = run[kEpt - 1u];
+      // Every wave owns a contiguous part of the table and walks it 256 slots per step: a lane reads ONE dword of
+      // marks (four consecutive slots) and writes ONE 16-byte vector of compact entries, both at consecutive
+      // addresses across the lanes -- (1 << P) / threads CONSECUTIVE slots per thread meant 8 ... 16 entry stores at an
+      // 8 ... 16-dword stride, i.e. that many lanes per LDS bank (the conflict k_ans_decode_pair's build had: section 4.4).
+      // All marks are in registers before the barrier that precedes the first entry store (they live in the LUT's tail).
+      static_assert(kCompact, "the scan build writes compact entries");
+      constexpr uint32_t kWaves = kDecThreads / 64u;
+      constexpr uint32_t kPart = (1u << P) / kWaves;  // slots per wave
+      static_assert(kPart % 256u == 0u, "");
+      constexpr uint32_t kSteps = kPart / 256u;
       auto dmax = [](uint32_t v, uint32_t o) { return v > o ? v : o; };
-      incl = dmax(incl, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true));
-      incl = dmax(incl, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true));
-      incl = dmax(incl, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true));
-      incl = dmax(incl, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true));
-      incl = dmax(incl, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xa, 0xf, true));
-      incl = dmax(incl, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, true));
-      uint32_t excl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x138, 0xf, 0xf, true);  // wave_shr:1
-      if (lane == 63u) sWaveTop[wave] = incl;
-      __syncthreads();
-      for (uint32_t w = 0; w < wave; ++w) excl = dmax(excl, sWaveTop[w]);
+      auto waveMaxScan = [&](uint32_t v) -> uint32_t {  // inclusive, DPP
+        v = dmax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
+        v = dmax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));
+        v = dmax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));
+        v = dmax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));
+        v = dmax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true));
+        v = dmax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true));
+        return v;
+      };
+      uint32_t m4[kSteps];
+      uint32_t top = 0;
 #pragma unroll
-      for (uint32_t j = 0; j < kEpt; ++j) {
-        const uint32_t x = tid * kEpt + j;
-        const uint32_t sym = dmax(run[j], excl);
-        if (kCompact) ((uint32_t*)sLut)[x] = (sPdf[sym] & 0xfffu) | (((x - sCdf[sym]) & 0xfffu) << 12) | (sym << 24);
-        else sLut[x] = make_uint2((sPdf[sym] & 0xfffu) | (sym << 24), (x - sCdf[sym]) & 0xfffu);
+      for (uint32_t t = 0; t < kSteps; ++t) {
+        m4[t] = ((const uint32_t*)sMark)[(wave * kPart + t * 256u) / 4u + lane];
+        const uint32_t a01 = dmax(m4[t] & 0xffu, (m4[t] >> 8) & 0xffu);
+        const uint32_t a23 = dmax((m4[t] >> 16) & 0xffu, m4[t] >> 24);
+        top = dmax(top, dmax(a01, a23));
+      }
+      top = waveMaxScan(top);
+      if (lane == 63u) sWaveTop[wave] = top;  // the largest mark of this wave's part
+      __syncthreads();
+      uint32_t carry = 0;  // the largest mark before the step (uniform)
+      for (uint32_t w = 0; w < wave; ++w) carry = dmax(carry, sWaveTop[w]);
+#pragma unroll
+      for (uint32_t t = 0; t < kSteps; ++t) {
+        uint32_t run[4];
+        run[0] = m4[t] & 0xffu;
+        run[1] = dmax(run[0], (m4[t] >> 8) & 0xffu);
+        run[2] = dmax(run[1], (m4[t] >> 16) & 0xffu);
+        run[3] = dmax(run[2], m4[t] >> 24);
+        const uint32_t incl = waveMaxScan(run[3]);
+        uint32_t excl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x138, 0xf, 0xf, true);  // wave_shr:1 (lane 0: 0)
+        excl = dmax(excl, carry);
+        uint32_t e[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+          const uint32_t x = wave * kPart + t * 256u + lane * 4u + j;
+          const uint32_t sym = dmax(run[j], excl);
+          e[j] = (sPdf[sym] & 0xfffu) | (((x - sCdf[sym]) & 0xfffu) << 12) | (sym << 24);
+        }
+        ((uint4*)sLut)[(wave * kPart + t * 256u) / 4u + lane] = make_uint4(e[0], e[1], e[2], e[3]);
+        carry = dmax(carry, (uint32_t)__builtin_amdgcn_readlane((int)incl, 63));
       }
     } else
     for (uint32_t x = tid; x < (1u << P); x += kDecThreads) {

@@ -112,11 +112,7 @@ struct EncodeArgs {
   uint64_t* tileDesc;        // [B][maxTiles], zeroed before launch (by the normalisation step)
   uint32_t* claims;          // [maxTiles][B] tile claim words, zeroed before launch
   uint32_t absentModulo;     // test hook: workgroups with index % absentModulo == 1 start ~0.5 ms late (0 = off)
-  uint16_t* spill;           // kSpill kernels only: [pairs][2][encSpillSlotWords(P)], one PAIR of slots per wavefront.
-                             // Persistent grids (spillFlags == null): wavefront w of workgroup g owns pair g * waves + w.
-                             // Hardware-dispatched grids: a wavefront that has to spill takes a pair (spillAcquire)
-  uint32_t* spillFlags;      // [spillPairs] 0 = free (zeroed by the normalisation step); null: static assignment
-  uint32_t spillPairs;       // >= the wavefronts of this kernel that can be resident at once
+  uint16_t* spill;           // [gridDim.x][blocks per tile][encSpillSlotWords(P)] (kSpill kernels only: persistent grids)
   uint32_t* outSize;         // [B] nullable
   uint32_t outCapacity;      // bytes the caller has at out.ptr(b): block data beyond it is NOT stored (outSize still
                              // reports the full size); 0xffffffff = the reference's contract (room for the maximum).
@@ -352,28 +348,6 @@ __device__ __forceinline__ void stageWriteShiftUnder(uint64_t vote, uint32_t add
                : [s] "+v"(state), [sv] "=&s"(saved) : [a] "v"(addr), [v] "s"(vote) : "memory", "scc");
 }
 
-// Spill slots of a hardware-dispatched grid (one workgroup per tile: blockIdx.x is no bound on what is resident).  A
-// wavefront whose blocks turn out not to fit its LDS stages takes a PAIR of slots (one per half) out of a pool with one
-// flag word per pair and gives it back after its copy-out.  The pool has at least as many pairs as wavefronts of the
-// kernel can be resident and a wavefront holds at most one, so the probe terminates.  Rare path (incompressible data).
-__device__ __forceinline__ uint32_t spillAcquire(uint32_t* flags, uint32_t pairs, uint32_t seed) {  // whole wavefront
-  uint32_t idx = 0;
-  if ((threadIdx.x & 63u) == 0u) {
-    uint32_t i = seed % pairs;
-    for (;;) {
-      uint32_t expected = 0;
-      if (__hip_atomic_compare_exchange_strong(flags + i, &expected, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-      i = i + 1u == pairs ? 0u : i + 1u;
-    }
-    idx = i;
-  }
-  return (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
-}
-__device__ __forceinline__ void spillRelease(uint32_t* flags, uint32_t pair) {  // whole wavefront, after its last read of the slots
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(flags + pair, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // Encodes the rows of one block per half-wave.  Returns the words left in the LDS stage; `spilledOut` = words
 // flushed to the spill slot (kSpill), `stateOut` = the lane's final state, `overrunOut` = the block emitted more
 // words than stage (+ spill slot) can hold.  That cannot happen with a table made from this data's histogram (the
@@ -392,11 +366,7 @@ constexpr uint32_t kEncGuardSlackWords = 192;
 static_assert(encGuardLimit(9, 120) + 256u <= encStageWords(9) + kEncGuardSlackWords &&
               encGuardLimit(10, 120) + 256u <= encStageWords(10) + kEncGuardSlackWords &&
               encGuardLimit(11, 120) + 256u <= encStageWords(11) + kEncGuardSlackWords, "");
-// kAbort (with kSpill): the FIRST attempt of k_ans_encode at a pair of blocks.  It has no spill slot; where the other
-// kSpill variant would flush, it gives up (`*abortedOut`, wave-uniform) and the caller encodes the two blocks again
-// with a slot.  The flush code -- a copy loop, 64-bit slot addresses -- then is not part of the row loop that every
-// tile runs, and a hardware-dispatched workgroup takes a slot only when it is certain to need one.
-template <int P, uint32_t FT, bool kFull, bool kSpill, bool kGuard = false, bool kAbort = false>
+template <int P, uint32_t FT, bool kFull, bool kSpill, bool kGuard = false>
 __device__ __forceinline__ uint32_t encodeRows(
     const ChunkSource<FT>& src,
     uint32_t n,                           // symbols in this half's block (0 = idle half)
@@ -409,9 +379,7 @@ __device__ __forceinline__ uint32_t encodeRows(
     uint16_t* __restrict__ spill,         // this half's spill slot (kSpill only)
     uint32_t& spilledOut,                 // words flushed to it (multiple of 8)
     uint32_t& stateOut,
-    bool& overrunOut,
-    bool* abortedOut = nullptr) {
-  static_assert(!kAbort || kSpill, "kAbort is a mode of the small-stage kernels");
+    bool& overrunOut) {
   const uint32_t laneMaskLt = (1u << hl) - 1u;
   uint32_t state = kStartState;
   uint32_t outOff = 0;
@@ -419,17 +387,15 @@ __device__ __forceinline__ uint32_t encodeRows(
   bool overrun = false;
 
   // Called every kFlushRows rows: make room for the next kFlushRows rows.
-  // Returns true (kAbort only, wave-uniform) if the rows cannot go on without a spill slot.
-  auto makeRoom = [&](uint32_t row) -> bool {
+  auto makeRoom = [&](uint32_t row) {
     if (!kSpill && kGuard && outOff > encGuardLimit(P, row)) {
       outOff = 0;
       overrun = true;
     }
-    if (!kSpill) return false;
+    if (!kSpill) return;
     const uint32_t o0 = __builtin_amdgcn_readlane(outOff, 0);
     const uint32_t o1 = __builtin_amdgcn_readlane(outOff, 32);
-    if ((o0 > o1 ? o0 : o1) + kFlushRows * 32u <= encStageCap(P, true, FT)) return false;  // wave-uniform
-    if (kAbort) return true;
+    if ((o0 > o1 ? o0 : o1) + kFlushRows * 32u <= encStageCap(P, true, FT)) return;  // wave-uniform
     // whole 16-byte vectors go to the spill slot, the (< 8 word) rest moves to the front
     uint32_t nvec = outOff >> 3;
     if (spilled + nvec * 8u > encSpillSlotWords(P)) {  // (only with a table that does not cover the data)
@@ -447,9 +413,7 @@ __device__ __forceinline__ uint32_t encodeRows(
     if (hl < rem) *(LdsU16e*)(uintptr_t)(stageBase + 2u * hl) = t;
     spilled += nvec * 8u;
     outOff = rem;
-    return false;
   };
-  bool aborted = false;
 
   // Generic step (partial blocks): predicated, emission under a branch.
   auto step = [&](const uint4 e, bool valid) {
@@ -515,16 +479,12 @@ __device__ __forceinline__ uint32_t encodeRows(
       for (int r = 0; r < kAhead; ++r) e[r] = fetchEntry(sym[r]);
 #pragma unroll
       for (int r = 0; r < (int)kChunkRows; ++r) {
-        if (r % kFlushRows == 0 && makeRoom(c * kChunkRows + (uint32_t)r)) {
-          aborted = true;
-          break;
-        }
+        if (r % kFlushRows == 0) makeRoom(c * kChunkRows + (uint32_t)r);
         const uint4 cur_e = e[r % kAhead];
         if (r + kAhead < (int)kChunkRows) e[r % kAhead] = fetchEntry(sym[(r + kAhead) % kSymAhead]);
         if (r + kSymAhead < (int)kChunkRows) sym[r % kSymAhead] = symAt(r + kSymAhead);
         stepFull(cur_e);
       }
-      if (kAbort && aborted) break;
     }
   } else {
     // Partial blocks, unaligned inputs, a wave with a single block: rows in groups
@@ -533,10 +493,7 @@ __device__ __forceinline__ uint32_t encodeRows(
     // round trip instead of one per row.
 #pragma unroll 1
     for (uint32_t row0 = 0; row0 < maxRows; row0 += kFlushRows) {
-      if (makeRoom(row0)) {
-        aborted = true;
-        break;
-      }
+      makeRoom(row0);
       uint32_t word[kFlushRows];
 #pragma unroll
       for (uint32_t j = 0; j < kFlushRows; ++j) {
@@ -570,7 +527,6 @@ __device__ __forceinline__ uint32_t encodeRows(
   spilledOut = spilled;
   stateOut = state;
   overrunOut = overrun;
-  if (kAbort) *abortedOut = aborted;
   return outOff;
 }
 
@@ -594,6 +550,12 @@ __device__ __forceinline__ uint32_t encodeRows(
 // claimed: the tile with the smallest (element-wise) index among the
 // unfinished ones never waits, so there is no deadlock at any residency.
 // With the whole grid resident nobody steals and this IS the static schedule.
+//
+// kPersistent = false (raw bytes only, capi.hip encoderHardwareDispatch): the same kernel launched with one workgroup
+// per ticket -- the hardware dispatches workgroups in index order as slots free up, so a slow CU simply takes fewer
+// tiles (256 x 1 MiB Zipf bytes: 152.7 -> 141.5 us).  The claim words stay: a workgroup still makes sure its element's
+// previous tile is claimed and encodes it first if it is not, so nothing depends on the dispatch order.  The float
+// kernels need per-workgroup spill slots, which only a persistent grid can index by blockIdx.x.
 //
 // Tile descriptors carry {status:2, ..., failed:1 (bit 40), words:32}: the padded word count of a tile (aggregate) or
 // of all tiles up to it (inclusive), and a sticky flag set by a tile that overran its stage (caller-supplied
@@ -623,8 +585,8 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
   uint16_t* stage = sStage + hw * kCap;
   const uint32_t stageLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)stage;
   const uint32_t tableLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)sTable;
-  // persistent grid: the wavefront's own pair of spill slots (pair = blockIdx.x * waves + wave)
-  uint16_t* const ownSlot = (kSpill && kPersistent) ? a.spill + ((size_t)blockIdx.x * kTB + hw) * encSpillSlotWords(P) : nullptr;
+  static_assert(kPersistent || !kSpill, "a hardware-dispatched grid has no spill slots: blockIdx.x does not bound what is resident");
+  uint16_t* spillSlot = kSpill ? a.spill + ((size_t)blockIdx.x * kTB + hw) * encSpillSlotWords(P) : nullptr;
 
   if (a.absentModulo && blockIdx.x % a.absentModulo == 1u) {
     // test hook: a workgroup that becomes resident late (~0.5 ms after the others)
@@ -735,46 +697,18 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
       uint32_t words;        // words left in the LDS stage
       uint32_t spilled = 0;  // words already in the spill slot
       bool overrun = false;
-      uint16_t* spillSlot = ownSlot;
-      uint32_t spillPair = 0;        // pair of slots taken from the pool (hardware-dispatched grids)
-      bool spillPairTaken = false;
-      // rows needed by the larger of the two halves (uniform; the partial-block path)
-      uint32_t nA = 0;
-      if (firstBlockOfWave < nb) {
-        uint32_t beginA = firstBlockOfWave * kBlockSize;
-        nA = size - beginA < kBlockSize ? size - beginA : kBlockSize;  // first half is never smaller than the second
-      }
-      if (kPersistent || !kSpill) {
-        if (waveFull || waveHalf) {
-          words = encodeRows<P, FT, true, kSpill>(src, n, kRowsPerBlock, tableLds, stageLds, sRing + hw * 512u, hl, upper,
-                                                  spillSlot, spilled, state, overrun);
-        } else {
-          words = encodeRows<P, FT, false, kSpill>(src, n, divUp(nA, 32u), tableLds, stageLds, nullptr, hl, upper, spillSlot,
-                                                   spilled, state, overrun);
-        }
+      if (waveFull || waveHalf) {
+        words = encodeRows<P, FT, true, kSpill>(src, n, kRowsPerBlock, tableLds, stageLds, sRing + hw * 512u, hl, upper,
+                                                spillSlot, spilled, state, overrun);
       } else {
-        // Hardware-dispatched grid: no slot is this wavefront's by right.  First attempt without one (kAbort): exponent
-        // streams fit the stage.  A wavefront whose blocks do not takes a pair from the pool and encodes them again.
-        bool aborted = false;
-        if (waveFull || waveHalf) {
-          words = encodeRows<P, FT, true, kSpill, false, kSpill>(src, n, kRowsPerBlock, tableLds, stageLds, sRing + hw * 512u, hl,
-                                                                 upper, nullptr, spilled, state, overrun, &aborted);
-        } else {
-          words = encodeRows<P, FT, false, kSpill, false, kSpill>(src, n, divUp(nA, 32u), tableLds, stageLds, nullptr, hl, upper,
-                                                                  nullptr, spilled, state, overrun, &aborted);
+        // rows needed by the larger of the two halves (uniform)
+        uint32_t nA = 0;
+        if (firstBlockOfWave < nb) {
+          uint32_t beginA = firstBlockOfWave * kBlockSize;
+          nA = size - beginA < kBlockSize ? size - beginA : kBlockSize;  // first half is never smaller than the second
         }
-        if (kSpill && aborted) {  // wave-uniform
-          spillPair = spillAcquire(a.spillFlags, a.spillPairs, blockIdx.x * (kTB / 2u) + wave);
-          spillPairTaken = true;
-          spillSlot = a.spill + ((size_t)spillPair * 2u + (upper ? 1u : 0u)) * encSpillSlotWords(P);
-          if (waveFull || waveHalf) {
-            words = encodeRows<P, FT, true, true>(src, n, kRowsPerBlock, tableLds, stageLds, sRing + hw * 512u, hl, upper, spillSlot,
-                                                  spilled, state, overrun);
-          } else {
-            words = encodeRows<P, FT, false, true>(src, n, divUp(nA, 32u), tableLds, stageLds, nullptr, hl, upper, spillSlot,
-                                                   spilled, state, overrun);
-          }
-        }
+        words = encodeRows<P, FT, false, kSpill>(src, n, divUp(nA, 32u), tableLds, stageLds, nullptr, hl, upper, spillSlot,
+                                                 spilled, state, overrun);
       }
 
       if (haveBlock) {
@@ -873,7 +807,6 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
         const uint4* s4 = (const uint4*)stage;
         for (uint32_t i = hl; i < vecs; i += 32u) streamStore<kNtEncStores>(&dst[i], s4[i]);
       }
-      if (kSpill && !kPersistent && spillPairTaken) spillRelease(a.spillFlags, spillPair);  // wave-uniform
     }  // tiles [tileLo, tile0] of element b
   }
 }

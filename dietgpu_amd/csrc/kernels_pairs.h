@@ -199,21 +199,23 @@ __global__ __launch_bounds__(64) void k_ans_encode_pair(EncodeArgs a) {
     uint8_t* archive = a.out.ptr(b);
     uint8_t* ans = archive + ansOffsetInArchive(FT, esize);
 
-    // This half's encoder table, from the 512-byte pdf table the normalisation left in the archive header (8
-    // symbols per lane).  A [B][256] x 16-byte table in HBM between the two kernels would be as many bytes as the
-    // exponent plane of a 4 Ki element, written once and read once.
+    // This half's encoder table, from the 512-byte pdf table the normalisation left in the archive header.  A
+    // [B][256] x 16-byte table in HBM between the two kernels would be as many bytes as the exponent plane of a 4 Ki
+    // element, written once and read once.  Lane hl builds the entries of symbols hl, hl + 32, ... (a row of 32
+    // symbols per step: cdf = the earlier rows' total + a 32-lane scan), so that a step's 16-byte entries go to
+    // CONSECUTIVE LDS addresses across the lanes -- eight consecutive symbols per lane put every lane of a half on the
+    // same four banks, 16 passes per store (the conflict k_ans_decode_pair's LUT build had).
     {
-      const uint4 raw = ((const uint4*)(ans + sizeof(AnsHeader)))[hl];  // pdf[8 hl .. 8 hl + 7]
-      const uint32_t pdf[8] = {raw.x & 0xffffu, raw.x >> 16, raw.y & 0xffffu, raw.y >> 16,
-                               raw.z & 0xffffu, raw.z >> 16, raw.w & 0xffffu, raw.w >> 16};
-      uint32_t mine = 0;
+      const uint16_t* pdfTable = (const uint16_t*)(ans + sizeof(AnsHeader));
+      uint32_t pdf[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) mine += pdf[j];
-      uint32_t cdf = halfInclusiveScanDpp(mine) - mine;
+      for (uint32_t j = 0; j < 8u; ++j) pdf[j] = pdfTable[j * 32u + hl];
+      uint32_t before = 0;  // probability mass of the earlier rows (uniform per half)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        sTable[8u * hl + (uint32_t)j] = encTableEntry(pdf[j], cdf, P);
-        cdf += pdf[j];
+      for (uint32_t j = 0; j < 8u; ++j) {
+        const uint32_t incl = halfInclusiveScanDpp(pdf[j]);
+        sTable[j * 32u + hl] = encTableEntry(pdf[j], before + incl - pdf[j], P);
+        before += upper ? (uint32_t)__builtin_amdgcn_readlane((int)incl, 63) : (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
       }
     }
 

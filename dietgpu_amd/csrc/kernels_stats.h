@@ -192,8 +192,6 @@ struct NormalizeArgs {
   uint32_t maxTiles;
   uint32_t* claims;          // [maxTiles][numInBatch] nullable (encoder's tile claim words)
   uint32_t numInBatch;
-  uint32_t* spillFlags;      // [spillPairs] nullable (hardware-dispatched encoder's spill pool, kernels_encode.h)
-  uint32_t spillPairs;
 };
 
 // The static part of the ANS archive header of element b (the fields ansEncodeCoalesce writes at
@@ -255,9 +253,6 @@ __device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const u
       a.tileDesc[(size_t)b * a.maxTiles + i] = 0;
       if (a.claims) a.claims[(size_t)i * a.numInBatch + b] = 0;
     }
-  }
-  if (a.spillFlags) {  // element b clears every numInBatch-th group of 256 flags
-    for (uint32_t i = b * 256u + tid; i < a.spillPairs; i += a.numInBatch * 256u) a.spillFlags[i] = 0;
   }
 
   if (total != 0) {

@@ -322,10 +322,11 @@ int dgpu_prof_summary(char* buf, size_t cap);
  * running workgroups take over the tiles of workgroups that have not started. */
 void dgpu_debug_set_absent_workgroups(uint32_t modulo);
 
-/* Measurement / test hook: how the workgroups of the tiled encoder (k_ans_encode; replaces the grid of
- * ansEncodeBatch, GpuANSEncode.cuh:429-461) come to their tiles.  -1 (default): the library decides per call;
- * 0: as many persistent workgroups as fit on the device, static ticket map; 1: one workgroup per tile, dispatched
- * by the hardware in ticket order.  Archives are byte-identical either way. */
+/* Measurement / test hook: how the workgroups of the tiled RAW-BYTE encoder (k_ans_encode<.., FT = 0, ..>; replaces the
+ * grid of ansEncodeBatch, GpuANSEncode.cuh:429-461) come to their tiles.  -1 (default): the library decides per call
+ * (one workgroup per tile when there are more tiles than resident workgroups); 0: as many persistent workgroups as fit
+ * on the device, static ticket map; 1: one workgroup per tile, dispatched by the hardware in ticket order.  Archives
+ * are byte-identical either way.  The float encoders always run persistent. */
 void dgpu_debug_set_encoder_dispatch(int mode);
 
 /* Measurement hook: 0 makes every pointer-array call upload its parameter block

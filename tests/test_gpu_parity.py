@@ -1649,50 +1649,19 @@ def test_capped_stride_compress_and_bounded_stride_decompress(dg, ft):
 # ----------------------------------------------------------------- encoder dispatch modes
 @pytest.mark.parametrize("mode", [0, 1])
 def test_encoder_dispatch_modes(dg, mode):
-    # k_ans_encode runs either as persistent workgroups with a static ticket map (0) or as one workgroup per tile
-    # dispatched by the hardware (1); the library picks per call, this hook forces one.  Archives are byte-identical to
-    # the oracle either way: spill path (incompressible floats: under hardware dispatch the slots come from the pool,
-    # after a first attempt without one), late workgroups, long look-back chains, ragged batches.
+    # The tiled raw-byte encoder runs either as persistent workgroups with a static ticket map (0) or as one workgroup
+    # per tile dispatched by the hardware (1); the library picks per call (more tiles than resident workgroups: 1), this
+    # hook forces one.  Archives are byte-identical to the oracle either way: late workgroups and the take-over of
+    # their tiles, look-back chains over 1027 tiles, ragged batches, BASELINE config 2.  (The float encoders are
+    # always persistent: the calls below that use them run unchanged.)
     L = dg.lib()
     L.dgpu_debug_set_encoder_dispatch(mode)
     try:
-        test_float_incompressible_exponents(dg, O.BFLOAT16, 10)
-        test_float_incompressible_exponents(dg, O.FLOAT16, 11)
-        test_float_incompressible_exponents(dg, O.FLOAT32, 9)
         test_encoder_with_absent_workgroups(dg, 3)
         test_lookback_windows_raw(dg, 129, 3)
         test_lookback_windows_raw(dg, 1027, 7)
         test_fuzz_ragged_batches(dg, 1)
+        test_fuzz_ragged_batches(dg, 4)
+        test_baseline_config2_zipf_bytes(dg)
     finally:
         L.dgpu_debug_set_encoder_dispatch(-1)
-
-
-def test_spill_pool_with_more_tiles_than_slots(dg):
-    # Incompressible bf16 words, 2300 tiles in few elements: under hardware dispatch every resident wavefront holds a
-    # pair of spill slots and later tiles wait for pairs to come back.  Checked against the persistent grid's archives
-    # (which test_float_incompressible_exponents pins to the oracle at oracle-friendly sizes) and by the round trip.
-    if getattr(dg, "name", "") == "torch_ops":
-        pytest.skip("same kernels as the ctypes surface")
-    L = dg.lib()
-    rng = np.random.default_rng(77)
-    ns = [4096 * 8 * 900 + 321, 4096 * 8 * 700, 4096 * 8 * 700 + 4000]
-    ts = [torch.from_numpy(rng.integers(0, 1 << 16, n, dtype=np.uint64).astype(np.uint16).view(np.int16)).to(DEV).view(torch.bfloat16)
-          for n in ns]
-    got = {}
-    for mode in (0, 1):
-        L.dgpu_debug_set_encoder_dispatch(mode)
-        try:
-            comp, sizes, _ = dg.compress_data(True, ts, False, prob_bits=10)
-            torch.cuda.synchronize()
-        finally:
-            L.dgpu_debug_set_encoder_dispatch(-1)
-        hs = sizes.cpu().numpy()
-        got[mode] = [comp[i, : hs[i]].clone() for i in range(len(ts))]
-    for a, b in zip(got[0], got[1]):
-        assert a.numel() == b.numel() and torch.equal(a, b)
-    outs = [torch.empty_like(t) for t in ts]
-    status = torch.zeros((len(ts),), dtype=torch.uint8, device=DEV)
-    dg.decompress_data(True, got[1], outs, False, None, status, None, prob_bits=10)
-    assert status.cpu().numpy().all()
-    for t, o in zip(ts, outs):
-        assert torch.equal(t.view(torch.int16), o.view(torch.int16))
