@@ -52,6 +52,7 @@ _SIGS = {
     "dgpu_prof_summary": (i32, [C.c_char_p, sz]),
     "dgpu_debug_set_absent_workgroups": (None, [u32]),
     "dgpu_debug_set_encoder_dispatch": (None, [i32]),
+    "dgpu_debug_set_decoder_order": (None, [i32]),
     "dgpu_debug_set_param_cache": (None, [i32]),
     "dgpu_set_histogram_load_policy": (None, [i32]),
     "dgpu_release_graph_state": (i32, []),

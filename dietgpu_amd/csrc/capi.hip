@@ -1214,6 +1214,23 @@ int floatCompressImpl(
   return rc;
 }
 
+// Order of k_ans_decode's workgroups (kernels_decode.h: decodeTileOf).  Measured on MI355X, cold round trip
+// (profiles/r05_ab_decoder_order.txt): with the tiles of an element back to back, eight consecutive workgroups -- one per
+// XCD -- read one archive and write one output row; letting every XCD walk its own elements spreads a moment's traffic
+// over eight times as many rows: 256 x 512 Ki bf16 decode 107 -> 102 us (step -1.7 %), fp16 -3.5 %, 64 x 2 Mi -4 %,
+// Zipf bytes -1 %.  It needs enough elements to keep the eight XCDs level (16 x 8 Mi: +17 % for the decoder alone, a
+// batch of one: everything on one XCD), so small batches keep the element-major order.  -1 = this policy;
+// dgpu_debug_set_decoder_order / DGPU_DEC_ORDER force an order (tests, A/B runs).
+std::atomic<int> g_decOrder{[] {
+  const char* e = getenv("DGPU_DEC_ORDER");
+  return e && *e ? atoi(e) : -1;
+}()};
+uint32_t decodeOrder(uint32_t B) {
+  const int forced = g_decOrder.load();
+  if (forced >= 0 && forced <= (int)kDecOrderXcd) return (uint32_t)forced;
+  return B >= 64u ? kDecOrderXcd : kDecOrderElementMajor;
+}
+
 template <int P, uint32_t FT>
 int launchDecodePF(const DecodeArgs& a, uint32_t tileBlocks, dim3 grid, hipStream_t stream) {
   if (tileBlocks == kDecBlocksPerSingleTile) {
@@ -1311,7 +1328,9 @@ int decodeImpl(
     d.inBytes = inBytes_dev;
     d.uniformInBytes = uniformInBytes;
     d.numInBatch = B;
-    dim3 grid(maxTiles, B);
+    d.maxTiles = maxTiles;
+    d.order = decodeOrder(B);
+    dim3 grid((d.order == kDecOrderXcd ? roundUp(B, 8u) : B) * maxTiles);
     int rc;
     if (ft == 0) rc = launchDecodeF<0>(P, d, tileBlocks, grid, stream);
     else if (ft == kFloat16) rc = launchDecodeF<kFloat16>(P, d, tileBlocks, grid, stream);
@@ -1412,6 +1431,7 @@ uint32_t absentWorkgroupModulo() { return g_absentModulo.load(); }
 extern "C" {
 void dgpu_debug_set_absent_workgroups(uint32_t modulo) { g_absentModulo.store(modulo); }
 void dgpu_debug_set_encoder_dispatch(int mode) { g_encDispatch.store(mode < 0 ? -1 : (mode != 0)); }
+void dgpu_debug_set_decoder_order(int order) { g_decOrder.store(order); }
 void dgpu_debug_set_param_cache(int on) { g_paramCacheEnabled.store(on != 0); }
 void dgpu_set_histogram_load_policy(int mode) { g_histLoadPolicy.store(mode < 0 ? -1 : (mode != 0)); }
 int dgpu_release_graph_state(void) {

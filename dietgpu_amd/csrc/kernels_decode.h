@@ -53,11 +53,39 @@ struct DecodeArgs {
   uint32_t* outSize;       // [B] nullable
   const uint32_t* inBytes; // [B] nullable: bytes available at in.ptr(b) (the *_bounded entry points); an archive
                            // that claims to be longer is rejected instead of being read past its buffer
-  uint32_t numInBatch;     // B (k_ans_decode_pair; the general kernel takes it from the grid)
+  uint32_t numInBatch;     // B
+  uint32_t maxTiles;       // k_ans_decode: tiles per element the 1-D grid is laid out for
+  uint32_t order;          // k_ans_decode: how workgroup index -> (element, tile), see decodeTileOf
   uint32_t uniformInBytes; // != 0 (and inBytes == nullptr): every archive has this many bytes available (stride batches)
 };
 __device__ __forceinline__ uint64_t decodeInBytes(const DecodeArgs& a, uint32_t b) {
   return a.inBytes ? (uint64_t)a.inBytes[b] : (a.uniformInBytes ? (uint64_t)a.uniformInBytes : ~0ull);
+}
+
+// Workgroup index -> (element, tile) of k_ans_decode's 1-D grid of B * maxTiles workgroups (kDecOrderXcd: B rounded up to 8).  The hardware
+// dispatches workgroups in index order, workgroup w on XCD w mod 8.
+//   kDecOrderElementMajor: w = b * T + tile -- the tiles of an element run back to back (rounds 1-4)
+//   kDecOrderTileMajor:    w = tile * B + b -- the order the encoder wrote the archives in
+//   kDecOrderXcd:          every XCD walks ITS elements (b mod 8 == XCD) element-major: consecutive workgroups touch
+//                          eight elements, and an element's header, pdf table and descriptors stay in one XCD's L2
+constexpr uint32_t kDecOrderElementMajor = 0, kDecOrderTileMajor = 1, kDecOrderXcd = 2;
+__device__ __forceinline__ bool decodeTileOf(const DecodeArgs& a, uint32_t w, uint32_t* b, uint32_t* tile) {
+  const uint32_t T = a.maxTiles, B = a.numInBatch;
+  if (a.order == kDecOrderTileMajor) {
+    *tile = w / B;
+    *b = w - *tile * B;
+    return *tile < T;
+  }
+  if (a.order == kDecOrderXcd) {
+    const uint32_t x = w & 7u, g = w >> 3;
+    const uint32_t e = g / T;
+    *tile = g - e * T;
+    *b = e * 8u + x;
+    return *b < B;
+  }
+  *b = w / T;
+  *tile = w - *b * T;
+  return *b < B;
 }
 
 // ---------------------------------------------------------------------------
@@ -533,8 +561,8 @@ __global__ __launch_bounds__(decThreads(kTileBlocks)) void k_ans_decode(DecodeAr
   const bool upper = lane >= 32u;
   const uint32_t hl = lane & 31u;
   const uint32_t hw = wave * 2u + (upper ? 1u : 0u);
-  const uint32_t b = blockIdx.y;
-  const uint32_t tile = blockIdx.x;
+  uint32_t b, tile;
+  if (!decodeTileOf(a, blockIdx.x, &b, &tile)) return;  // uniform (kDecOrderXcd pads the grid to a multiple of 8 elements)
 
   const uint8_t* archive = a.in.ptr(b);
   uint32_t floatSize = 0;

@@ -329,6 +329,11 @@ void dgpu_debug_set_absent_workgroups(uint32_t modulo);
  * are byte-identical either way.  The float encoders always run persistent. */
 void dgpu_debug_set_encoder_dispatch(int mode);
 
+/* Measurement / test hook: the order in which the workgroups of the tiled decoder (k_ans_decode; replaces the grid of
+ * ansDecodeBatch, GpuANSDecode.cuh:299-403) take the (element, tile) pairs.  -1 (default): the library decides per
+ * call; 0: element-major; 1: tile-major; 2: every XCD walks its own elements.  Outputs are identical either way. */
+void dgpu_debug_set_decoder_order(int order);
+
 /* Measurement hook: 0 makes every pointer-array call upload its parameter block
  * (no reuse of blocks already resident on the device); 1 (default) restores the
  * cache.  bench.py uses it to report the step time without the cache next to the

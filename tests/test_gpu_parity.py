@@ -1665,3 +1665,38 @@ def test_encoder_dispatch_modes(dg, mode):
         test_baseline_config2_zipf_bytes(dg)
     finally:
         L.dgpu_debug_set_encoder_dispatch(-1)
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_decoder_workgroup_orders(dg, order):
+    # k_ans_decode's 1-D grid maps workgroup index -> (element, tile) element-major, tile-major or per XCD (every XCD
+    # walks the elements b = XCD mod 8); the library picks by batch size, this hook forces one.  Batch sizes below,
+    # at and off the multiples of eight, ragged element sizes (tiles beyond an element's end), both tile shapes,
+    # raw bytes and floats: decoded data identical, status and sizes as reported by the default order.
+    L = dg.lib()
+    rng = np.random.default_rng(300 + order)
+    L.dgpu_debug_set_decoder_order(order)
+    try:
+        for B in (1, 3, 8, 13, 70):
+            ns = [int(rng.integers(1, 40)) * 4096 * int(rng.choice([1, 9])) + int(rng.integers(0, 4096)) for _ in range(B)]
+            ns[0] = 4096 * 16 * 5  # whole tiles
+            ws = [refgen.generate_floats(O.BFLOAT16, n) for n in ns]
+            ts = [words_to_tensor(O.BFLOAT16, w) for w in ws]
+            comp, sizes, _ = dg.compress_data(True, ts, False, prob_bits=10)
+            hs = sizes.cpu().numpy()
+            arch = [comp[i, : hs[i]].clone() for i in range(B)]
+            outs = [torch.empty_like(t) for t in ts]
+            status = torch.zeros((B,), dtype=torch.uint8, device=DEV)
+            osz = torch.zeros((B,), dtype=torch.int32, device=DEV)
+            dg.decompress_data(True, arch, outs, False, None, status, osz, prob_bits=10)
+            assert status.cpu().numpy().all() and (osz.cpu().numpy() == np.array(ns)).all()
+            for w, o in zip(ws, outs):
+                assert (tensor_to_words(O.BFLOAT16, o) == w).all()
+        xs = [rng.integers(0, 90, int(n), dtype=np.uint8) for n in (4096 * 16 * 3 + 5, 100, 4096 * 40, 4096 * 16)]
+        got = gpu_ans_encode(dg, xs, 10)
+        outs, status, osz = gpu_ans_decode(dg, got, [x.size for x in xs], 10)
+        assert status.all()
+        for x, o in zip(xs, outs):
+            assert (o == x).all()
+    finally:
+        L.dgpu_debug_set_decoder_order(-1)
