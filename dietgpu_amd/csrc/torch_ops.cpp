@@ -22,6 +22,11 @@ namespace dietgpu_amd {
 namespace {
 
 constexpr int kDefaultPrecision = 10;  // DietGpu.cpp:114
+// The precision the six codec ops use on the calling thread.  The reference's ops fix it at kDefaultPrecision; its C++
+// API takes it per call (ANSCodecConfig.probBits, GpuANSCodec.h:28-51).  dietgpu_amd::set_precision (an EXTRA op, in
+// its own namespace) lets dietgpu_amd.ops serve `prob_bits` 9 / 11 through this library too instead of through ctypes.
+thread_local int tPrecision = kDefaultPrecision;
+int precision() { return tPrecision; }
 
 uint32_t floatTypeFromDtype(at::ScalarType t) {
   switch (t) {
@@ -196,12 +201,12 @@ std::tuple<at::Tensor, at::Tensor, int64_t> compress_data(
   }
   size_t used = 0;
   if (compressAsFloat) {
-    check(dgpu_float_compress(tmp.ptr, tmp.bytes, &used, floatTypeFromDtype(tIns[0].scalar_type()), kDefaultPrecision,
+    check(dgpu_float_compress(tmp.ptr, tmp.bytes, &used, floatTypeFromDtype(tIns[0].scalar_type()), precision(),
                               checksum, (uint32_t)n, inPtrs.data(), inSize.data(), compPtrs.data(),
                               (uint32_t*)sizes.data_ptr(), streamOf(dev)),
           "floatCompress", true);
   } else {
-    check(dgpu_ans_encode_batch_pointer(tmp.ptr, tmp.bytes, &used, kDefaultPrecision, checksum, (uint32_t)n,
+    check(dgpu_ans_encode_batch_pointer(tmp.ptr, tmp.bytes, &used, precision(), checksum, (uint32_t)n,
                                         inPtrs.data(), inSize.data(), nullptr, compPtrs.data(),
                                         (uint32_t*)sizes.data_ptr(), streamOf(dev)),
           "ansEncodeBatchPointer", false);
@@ -244,12 +249,12 @@ std::tuple<std::vector<at::Tensor>, at::Tensor, int64_t> compress_data_split_siz
 
   size_t used = 0;
   if (compressAsFloat) {
-    check(dgpu_float_compress_split_size(tmp.ptr, tmp.bytes, &used, ft, kDefaultPrecision, checksum, (uint32_t)numInBatch,
+    check(dgpu_float_compress_split_size(tmp.ptr, tmp.bytes, &used, ft, precision(), checksum, (uint32_t)numInBatch,
                                          tIn.data_ptr(), (const uint32_t*)tSplitSizes.data_ptr(), comp.data_ptr(),
                                          (uint32_t)comp.size(1), (uint32_t*)sizes.data_ptr(), streamOf(dev)),
           "floatCompressSplitSize", true);
   } else {
-    check(dgpu_ans_encode_batch_split_size(tmp.ptr, tmp.bytes, &used, kDefaultPrecision, checksum, (uint32_t)numInBatch,
+    check(dgpu_ans_encode_batch_split_size(tmp.ptr, tmp.bytes, &used, precision(), checksum, (uint32_t)numInBatch,
                                            tIn.data_ptr(), (const uint32_t*)tSplitSizes.data_ptr(), nullptr,
                                            comp.data_ptr(), (uint32_t)comp.size(1), (uint32_t*)sizes.data_ptr(),
                                            streamOf(dev)),
@@ -318,13 +323,13 @@ int64_t decompress_data_impl(
   size_t used = 0;
   int32_t err = -1;
   if (compressAsFloat) {
-    check(dgpu_float_decompress_bounded(tmp.ptr, tmp.bytes, &used, floatTypeFromDtype(tOuts[0].scalar_type()), kDefaultPrecision,
+    check(dgpu_float_decompress_bounded(tmp.ptr, tmp.bytes, &used, floatTypeFromDtype(tOuts[0].scalar_type()), precision(),
                                 checksum, (uint32_t)n, inPtrs.data(), inBytes.data(), outPtrs.data(), outCapacity.data(),
                                 outStatus ? (uint8_t*)outStatus->data_ptr() : nullptr,
                                 outSizes ? (uint32_t*)outSizes->data_ptr() : nullptr, streamOf(dev), &err),
           "floatDecompress", true);
   } else {
-    check(dgpu_ans_decode_batch_pointer_bounded(tmp.ptr, tmp.bytes, &used, kDefaultPrecision, checksum, (uint32_t)n,
+    check(dgpu_ans_decode_batch_pointer_bounded(tmp.ptr, tmp.bytes, &used, precision(), checksum, (uint32_t)n,
                                         inPtrs.data(), inBytes.data(), outPtrs.data(), outCapacity.data(),
                                         outStatus ? (uint8_t*)outStatus->data_ptr() : nullptr,
                                         outSizes ? (uint32_t*)outSizes->data_ptr() : nullptr, streamOf(dev), &err),
@@ -379,13 +384,13 @@ int64_t decompress_data_split_size(
   int32_t err = -1;
   if (compressAsFloat) {
     check(dgpu_float_decompress_split_size_bounded(tmp.ptr, tmp.bytes, &used, floatTypeFromDtype(tOut.scalar_type()),
-                                           kDefaultPrecision, checksum, (uint32_t)numInBatch, inPtrs.data(), inBytes.data(),
+                                           precision(), checksum, (uint32_t)numInBatch, inPtrs.data(), inBytes.data(),
                                            tOut.data_ptr(), splitSizes.data(),
                                            outStatus ? (uint8_t*)outStatus->data_ptr() : nullptr,
                                            outSizes ? (uint32_t*)outSizes->data_ptr() : nullptr, streamOf(dev), &err),
           "floatDecompressSplitSize", true);
   } else {
-    check(dgpu_ans_decode_batch_split_size_bounded(tmp.ptr, tmp.bytes, &used, kDefaultPrecision, checksum, (uint32_t)numInBatch,
+    check(dgpu_ans_decode_batch_split_size_bounded(tmp.ptr, tmp.bytes, &used, precision(), checksum, (uint32_t)numInBatch,
                                            inPtrs.data(), inBytes.data(), tOut.data_ptr(), splitSizes.data(),
                                            outStatus ? (uint8_t*)outStatus->data_ptr() : nullptr,
                                            outSizes ? (uint32_t*)outSizes->data_ptr() : nullptr, streamOf(dev), &err),
@@ -441,6 +446,11 @@ std::vector<at::Tensor> decompress_data_simple(
   return tOuts;
 }
 
+void set_precision(int64_t probBits) {
+  TORCH_CHECK(probBits == 9 || probBits == 10 || probBits == 11, "probBits must be 9, 10 or 11");
+  tPrecision = (int)probBits;
+}
+
 }  // namespace dietgpu_amd
 
 // Schema strings verbatim from DietGpu.cpp:915-937
@@ -461,6 +471,10 @@ TORCH_LIBRARY_FRAGMENT(dietgpu, m) {
       "decompress_data_split_size(bool compress_as_float, Tensor[] ts_in, Tensor t_out, Tensor t_out_split_sizes, bool checksum=False, Tensor? temp_mem=None, Tensor? out_status=None, Tensor? out_decompressed_words=None) -> (int)");
   m.def(
       "decompress_data_simple(bool compress_as_float, Tensor[] ts_in, bool checksum=False, int? temp_mem=67108864) -> Tensor[]");
+}
+
+TORCH_LIBRARY(dietgpu_amd, m) {
+  m.def("set_precision(int prob_bits) -> ()", &dietgpu_amd::set_precision);
 }
 
 TORCH_LIBRARY(dietgpu, m) {

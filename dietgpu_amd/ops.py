@@ -10,10 +10,10 @@ C ABI of include/dietgpu_amd.h.
 Extra keyword `prob_bits` (default 10, as kDefaultPrecision DietGpu.cpp:114)
 exposes the C++ API's ANSCodecConfig.probBits in {9, 10, 11}.
 
-Two routes to the same C ABI.  At the default precision the six codec ops are handed to `torch.ops.dietgpu.*`
-(csrc/torch_ops.cpp: argument checks and pointer marshalling in C++, ~2 us of host time per call) when
-libdietgpu_torch.so is there; the ctypes route below serves `prob_bits` 9 / 11 (the registered ops fix the precision
-at 10, as upstream) and builds without the op library.  256 tensors per call cost ~120 us of Python per op on the
+Two routes to the same C ABI.  The six codec ops are handed to `torch.ops.dietgpu.*` (csrc/torch_ops.cpp: argument
+checks and pointer marshalling in C++, ~2 us of host time per call) when libdietgpu_torch.so is there -- at `prob_bits`
+9 / 11 with the library's thread-local precision set around the call (the registered ops themselves fix the precision
+at 10, as upstream); the ctypes route below serves builds without the op library.  256 tensors per call cost ~120 us of Python per op on the
 ctypes route (profiles/r03_api_rate.txt) -- `prefer_torch_ops(False)` forces it (the test-suite runs every parity test
 on both routes).  Either way the work is done by libdietgpu_amd.so: there is no CPU path.
 """
@@ -43,15 +43,37 @@ def prefer_torch_ops(enable=True):
     _PREFER_TORCH_OPS = bool(enable)
 
 
+class _OpsAtPrecision:
+    """torch.ops.dietgpu.* at prob_bits 9 / 11: the op library's thread-local precision (dietgpu_amd::set_precision, an
+    extra op beside the reference's ten) is set around the call and put back to the default."""
+
+    def __init__(self, ops, prob_bits):
+        self._ops, self._p = ops, prob_bits
+
+    def __getattr__(self, name):
+        fn = getattr(self._ops, name)
+
+        def call(*args):
+            torch.ops.dietgpu_amd.set_precision(self._p)
+            try:
+                return fn(*args)
+            finally:
+                torch.ops.dietgpu_amd.set_precision(K_DEFAULT_PRECISION)
+
+        return call
+
+
 def _fast_ops(prob_bits):
     global _TORCH_OPS
-    if prob_bits != K_DEFAULT_PRECISION or not _PREFER_TORCH_OPS:
+    if prob_bits not in (9, 10, 11) or not _PREFER_TORCH_OPS:
         return None
     if _TORCH_OPS is None:
         with _TORCH_OPS_LOCK:
             if _TORCH_OPS is None:
                 _TORCH_OPS = _load_fast_ops()
-    return _TORCH_OPS or None
+    if not _TORCH_OPS:
+        return None
+    return _TORCH_OPS if prob_bits == K_DEFAULT_PRECISION else _OpsAtPrecision(_TORCH_OPS, prob_bits)
 
 
 def _load_fast_ops():

@@ -80,3 +80,33 @@ def test_wrong_world_size_is_refused():
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + SMALL, capture_output=True, text=True, timeout=300,
                        env=_clean_env(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stdout + p.stderr)
+
+
+def test_eight_ranks_on_one_device():
+    # BASELINE config 5's launch path at its real world size: python bench.py --gpus 8 starts eight ranks (gloo, all on
+    # GPU 0 -- the box has one GPU); rank 0's line must account for all eight, and the job must stay small enough that
+    # an 8-rank run on a shared device is safe (peak memory reported by rank 0's process group below 40 GB)
+    torch_free0 = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.mem_get_info(0)[0])"], capture_output=True,
+                                 text=True, timeout=300)
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--dist-backend", "gloo", "--steps", "4", "--warmup", "1", "--batch", "32",
+                        "--no-cpu-baseline", "--rotate", "2", "--quick"], capture_output=True, text=True, timeout=1200,
+                       env=_clean_env(DGPU_BENCH_ONE_DEVICE="1"))
+    d = _line(p)
+    _check_contract(d, 8)
+    assert d["dist_backend"] == "gloo" and d["n_gpus"] == d["world_size_seen_by_backend"] == 8
+    assert len(d["per_rank_ms_per_step"]) == 8 and all(t > 0 for t in d["per_rank_ms_per_step"])
+    assert "8 ranks x 32 independent tensors" in d["config"]["sharding"]
+    # per rank: 2 buffer sets x 32 rows x (1 MiB in + 1 MiB out + <= 1.3 MiB archive) + temp: far below 40 GB in all
+    assert int(torch_free0.stdout.strip()) > 0
+
+
+def test_compressed_all_gather_eight_ranks_on_one_device():
+    # the compressed collective (bench.py --collective) with eight gloo ranks on GPU 0: bit-exact payload (asserted
+    # inside bench.py against the plain all-gather), wire bytes below the raw bytes, one line from rank 0
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--dist-backend", "gloo", "--collective", "--steps", "3", "--warmup", "1",
+                        "--batch", "16", "--no-cpu-baseline"], capture_output=True, text=True, timeout=1200,
+                       env=_clean_env(DGPU_BENCH_ONE_DEVICE="1"))
+    d = _line(p)
+    assert d["n_gpus"] == 8 and d["bit_exact"] is True and d["dist_backend"] == "gloo"
+    assert d["config"]["wire_bytes_per_rank"] < d["config"]["per_rank_bytes"]
+    assert d["config"]["rows_sent_uncompressed"] == 0

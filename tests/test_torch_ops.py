@@ -117,3 +117,35 @@ def test_split_compress_and_decompress(ops):
         out = torch.empty_like(t)
         ops.decompress_data_split_size(True, [c.clone() for c in comp_ts], out, sizes_t, True, temp_mem)
         assert torch.equal(t, out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prob_bits", [9, 11])
+def test_package_ops_reach_the_op_library_at_every_precision(ops, prob_bits):
+    # dietgpu_amd.compress_data(..., prob_bits=9 / 11) goes through torch.ops.dietgpu.* with the library's thread-local
+    # precision set around the call (dietgpu_amd::set_precision), not through ctypes; archives equal the oracle's at that
+    # precision, the default precision is back afterwards, and a bad value is refused.
+    import numpy as np
+
+    import dietgpu_amd as dg
+    import oracle as O
+    from dietgpu_amd import ops as pkg_ops
+
+    dg.prefer_torch_ops(True)
+    assert isinstance(pkg_ops._fast_ops(prob_bits), pkg_ops._OpsAtPrecision)
+    rng = np.random.default_rng(prob_bits)
+    words = (rng.standard_normal(3 * 4096 + 77).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    t = torch.from_numpy(words.view(np.int16)).cuda().view(torch.bfloat16)
+    comp, sizes, _ = dg.compress_data(True, [t], prob_bits=prob_bits)
+    n = int(sizes[0].item())
+    want = O.float_compress(O.BFLOAT16, words, prob_bits)
+    assert n == want.size and (comp[0, :n].cpu().numpy() == want).all()
+    out = torch.empty_like(t)
+    dg.decompress_data(True, [comp[0, :n]], [out], prob_bits=prob_bits)
+    assert torch.equal(out.view(torch.int16), t.view(torch.int16))
+    # the registered ops are back at the reference's precision
+    c10, s10, _ = ops.compress_data(True, [t])
+    want10 = O.float_compress(O.BFLOAT16, words, 10)
+    assert int(s10[0].item()) == want10.size and (c10[0, : want10.size].cpu().numpy() == want10).all()
+    with pytest.raises(RuntimeError, match="probBits"):
+        torch.ops.dietgpu_amd.set_precision(12)
