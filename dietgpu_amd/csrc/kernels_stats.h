@@ -484,17 +484,20 @@ __global__ __launch_bounds__(256) void k_histogram(BatchView in, uint32_t* __res
 
   if (blockIdx.x == 0 && tid < head) histAdd<S>(myBins, p[tid]);
 
-  // four 16-byte loads in flight per lane (the kernel is HBM-latency bound otherwise)
-  const uint32_t stride = gridDim.x * 256u;
-  uint32_t i = blockIdx.x * 256u + tid;
-  for (; i + 3u * stride < numVec; i += 4u * stride) {
-    const uint4 v0 = streamLoad<kNt>(&pv[i]), v1 = streamLoad<kNt>(&pv[i + stride]), v2 = streamLoad<kNt>(&pv[i + 2u * stride]), v3 = streamLoad<kNt>(&pv[i + 3u * stride]);
+  // Every workgroup streams ONE contiguous part of the element (whole 16 KiB steps; the last part takes the rest), four
+  // 16-byte loads in flight per lane (the kernel is HBM-latency bound otherwise); see k_float_histogram.
+  const uint32_t perPart = roundUp(divUp(numVec, gridDim.x), 1024u);
+  const uint32_t vBegin = blockIdx.x * perPart < numVec ? blockIdx.x * perPart : numVec;
+  const uint32_t vEnd = vBegin + perPart < numVec ? vBegin + perPart : numVec;
+  uint32_t i = vBegin + tid;
+  for (; i + 768u < vEnd; i += 1024u) {
+    const uint4 v0 = streamLoad<kNt>(&pv[i]), v1 = streamLoad<kNt>(&pv[i + 256u]), v2 = streamLoad<kNt>(&pv[i + 512u]), v3 = streamLoad<kNt>(&pv[i + 768u]);
     histAdd4<S>(myBins, v0.x); histAdd4<S>(myBins, v0.y); histAdd4<S>(myBins, v0.z); histAdd4<S>(myBins, v0.w);
     histAdd4<S>(myBins, v1.x); histAdd4<S>(myBins, v1.y); histAdd4<S>(myBins, v1.z); histAdd4<S>(myBins, v1.w);
     histAdd4<S>(myBins, v2.x); histAdd4<S>(myBins, v2.y); histAdd4<S>(myBins, v2.z); histAdd4<S>(myBins, v2.w);
     histAdd4<S>(myBins, v3.x); histAdd4<S>(myBins, v3.y); histAdd4<S>(myBins, v3.z); histAdd4<S>(myBins, v3.w);
   }
-  for (; i < numVec; i += stride) {
+  for (; i < vEnd; i += 256u) {
     const uint4 v = streamLoad<kNt>(&pv[i]);
     histAdd4<S>(myBins, v.x);
     histAdd4<S>(myBins, v.y);
