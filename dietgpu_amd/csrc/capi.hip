@@ -145,7 +145,7 @@ struct StreamState {
   // dgpu_release_graph_state); slabInGraph: the current slab is such a slab
   bool slabInGraph = false;
   std::vector<void*> graphSlabs;
-  // 65536 arrival counters + kAccElements x 256 histogram counters (zero at rest)
+  // 65536 arrival counters + kAccElements x 256 histogram counters + 16384 spill-pool flags (zero at rest)
   uint32_t* counters = nullptr;
   // a call was CAPTURED into a HIP graph with pointers into this state (slab, counters): the graph replays without
   // passing through the library, so the state is never trimmed or released implicitly (dgpu_release_graph_state)
@@ -825,6 +825,8 @@ uint32_t encodePairGridPF(uint32_t elements) {
     }
     return (uint32_t)n;
   }();
+  // (workgroups = wavefronts that can be resident at once: the size of the spill-slot pool; the LAUNCH is one
+  // workgroup per pair, encodeCommon)
   return std::max(1u, std::min((elements + 1u) / 2u, perCu * numComputeUnits()));
 }
 template <int P, uint32_t FT>
@@ -943,7 +945,8 @@ bool histAccumulates(uint32_t B, uint32_t maxBytes, bool raw) {
 // ordered while calls on different streams may overlap.
 constexpr size_t kCounterWordsArrive = 65536;
 constexpr size_t kCounterWordsAcc = (size_t)kAccElements * kNumSymbols;
-int arrivalCounters(StreamLease& lease, uint32_t** out, uint32_t** acc) {
+constexpr size_t kCounterWordsSpill = 16384;  // flags of k_ans_encode_pair's spill-slot pool (kernels_encode.h: SpillPool)
+int arrivalCounters(StreamLease& lease, uint32_t** out, uint32_t** acc, uint32_t** spillFlags = nullptr) {
   hipError_t e = hipSuccess;
   StreamState* s = lease.state(&e);
   if (!s) return fail(DGPU_ERR_HIP, std::string("stream state: ") + hipGetErrorString(e));
@@ -953,7 +956,7 @@ int arrivalCounters(StreamLease& lease, uint32_t** out, uint32_t** acc) {
                                 "the stream is being captured: run the same call once before capturing");
     }
     uint32_t* p = nullptr;
-    const size_t words = kCounterWordsArrive + kCounterWordsAcc;
+    const size_t words = kCounterWordsArrive + kCounterWordsAcc + kCounterWordsSpill;
     DGPU_HIP(hipMalloc((void**)&p, words * sizeof(uint32_t)));
     // once per (device, stream), ordered on the caller's stream ahead of the kernels that use the
     // counters (a plain hipMemset runs on the null stream, which non-blocking streams do not wait for)
@@ -966,6 +969,7 @@ int arrivalCounters(StreamLease& lease, uint32_t** out, uint32_t** acc) {
   }
   *out = s->counters;
   *acc = s->counters + kCounterWordsArrive;
+  if (spillFlags) *spillFlags = s->counters + kCounterWordsArrive + kCounterWordsAcc;
   return DGPU_OK;
 }
 
@@ -1027,11 +1031,22 @@ int encodeCommon(
   const uint32_t resident = maxTiles > 0 ? encodeGrid(P, floatType, tileBlocks, numTickets) : 0u;
   const bool hwDispatch = tileBlocks != kBlocksPerSingleTile && encoderHardwareDispatch(numTickets, resident, floatType);
   uint16_t* spill = nullptr;
+  uint32_t* spillFlags = nullptr;
+  uint32_t spillPairs = 0;
   if (maxTiles > 0 && encodeSpills(floatType)) {
     // (single-block batches: two slots per workgroup, one per element of its pair)
     const uint32_t slotsPerWg = tileBlocks == kBlocksPerSingleTile ? 2u : tileBlocks;
     DGPU_ALLOC(sp, uint16_t, arena, (size_t)resident * slotsPerWg * encSpillSlotWords(P));
     spill = sp;
+    if (tileBlocks == kBlocksPerSingleTile) {
+      // k_ans_encode_pair runs one workgroup per pair: its slots are a pool of `resident` pairs, handed out through
+      // library-owned flags that are zero at rest
+      uint32_t *arrive = nullptr, *acc = nullptr;
+      int rc = arrivalCounters(lease, &arrive, &acc, &spillFlags);
+      if (rc) return rc;
+      spillPairs = resident;
+      DGPU_REQUIRE(spillPairs <= kCounterWordsSpill, "more resident encoder wavefronts than spill-pool flags");
+    }
   }
 
   NormalizeArgs n;
@@ -1128,7 +1143,8 @@ int encodeCommon(
     DGPU_HIP(hipGetLastError());
   }
   if (maxTiles > 0) {
-    const uint32_t grid = hwDispatch ? numTickets : resident;
+    // (k_ans_encode_pair: one workgroup per pair of elements; numTickets counts elements there)
+    const uint32_t grid = tileBlocks == kBlocksPerSingleTile ? (numTickets + 1u) / 2u : (hwDispatch ? numTickets : resident);
     EncodeArgs e;
     e.in = in;
     e.out = archives;
@@ -1140,6 +1156,8 @@ int encodeCommon(
     e.claims = claims;
     e.absentModulo = absentWorkgroupModulo();
     e.spill = spill;
+    e.spillFlags = spillFlags;
+    e.spillPairs = spillPairs;
     e.outSize = outSize_dev;
     e.outCapacity = outCapacity;
     e.useChecksum = (useChecksum && floatType) ? 1 : 0;

@@ -112,7 +112,11 @@ struct EncodeArgs {
   uint64_t* tileDesc;        // [B][maxTiles], zeroed before launch (by the normalisation step)
   uint32_t* claims;          // [maxTiles][B] tile claim words, zeroed before launch
   uint32_t absentModulo;     // test hook: workgroups with index % absentModulo == 1 start ~0.5 ms late (0 = off)
-  uint16_t* spill;           // [gridDim.x][blocks per tile][encSpillSlotWords(P)] (kSpill kernels only: persistent grids)
+  uint16_t* spill;           // kSpill kernels only.  k_ans_encode (persistent grids): [gridDim.x][blocks per tile]
+                             // [encSpillSlotWords(P)], a workgroup's slots are its own.  k_ans_encode_pair (one workgroup
+                             // per pair, dispatched by the hardware): [spillPairs][2][encSpillSlotWords(P)], a POOL
+  uint32_t* spillFlags;      // k_ans_encode_pair: [spillPairs] 0 = free; library-owned, zero at rest (SpillPool)
+  uint32_t spillPairs;       // ... >= the wavefronts of the kernel that can be resident at once
   uint32_t* outSize;         // [B] nullable
   uint32_t outCapacity;      // bytes the caller has at out.ptr(b): block data beyond it is NOT stored (outSize still
                              // reports the full size); 0xffffffff = the reference's contract (room for the maximum).
@@ -348,6 +352,48 @@ __device__ __forceinline__ void stageWriteShiftUnder(uint64_t vote, uint32_t add
                : [s] "+v"(state), [sv] "=&s"(saved) : [a] "v"(addr), [v] "s"(vote) : "memory", "scc");
 }
 
+// Spill slots of a hardware-dispatched grid (k_ans_encode_pair: one workgroup per pair of elements, so blockIdx.x is no
+// bound on what is resident).  A wavefront that has to flush takes a PAIR of slots (one per half) out of a pool with
+// one flag word per pair and gives it back after its copy-out.  The pool has at least as many pairs as wavefronts of
+// the kernel can be resident and a wavefront holds at most one, so the probe terminates; the flags are zero at rest.
+// A slot changes hands between wavefronts on DIFFERENT XCDs, whose L2s are not coherent with each other: everything
+// written to or read from a pooled slot goes through agent-scope accesses (write-through stores, L2-bypassing loads --
+// the hand-off discipline of the look-back descriptors).  Rare path: incompressible data only.
+struct SpillPool {
+  uint16_t* base;
+  uint32_t* flags;
+  uint32_t pairs;
+  uint32_t pair;  // kNoSpillPair until this wavefront has taken one (for the current pair of elements)
+};
+constexpr uint32_t kNoSpillPair = 0xffffffffu;
+__device__ __forceinline__ uint32_t spillAcquire(const SpillPool& sp, uint32_t seed) {  // whole wavefront
+  uint32_t idx = 0;
+  if ((threadIdx.x & 63u) == 0u) {
+    uint32_t i = seed % sp.pairs;
+    for (;;) {
+      uint32_t expected = 0;
+      if (__hip_atomic_compare_exchange_strong(sp.flags + i, &expected, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      i = i + 1u == sp.pairs ? 0u : i + 1u;
+    }
+    idx = i;
+  }
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+}
+__device__ __forceinline__ void spillRelease(SpillPool& sp) {  // whole wavefront, after its last read of the slots
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(sp.flags + sp.pair, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  sp.pair = kNoSpillPair;
+}
+__device__ __forceinline__ void coherentStore16(uint4* p, const uint4& v) {
+  __hip_atomic_store((uint64_t*)p, (uint64_t)v.x | ((uint64_t)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store((uint64_t*)p + 1, (uint64_t)v.z | ((uint64_t)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint4 coherentLoad16(const uint4* p) {
+  const uint64_t lo = __hip_atomic_load((const uint64_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint64_t hi = __hip_atomic_load((const uint64_t*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
+
 // Encodes the rows of one block per half-wave.  Returns the words left in the LDS stage; `spilledOut` = words
 // flushed to the spill slot (kSpill), `stateOut` = the lane's final state, `overrunOut` = the block emitted more
 // words than stage (+ spill slot) can hold.  That cannot happen with a table made from this data's histogram (the
@@ -366,7 +412,8 @@ constexpr uint32_t kEncGuardSlackWords = 192;
 static_assert(encGuardLimit(9, 120) + 256u <= encStageWords(9) + kEncGuardSlackWords &&
               encGuardLimit(10, 120) + 256u <= encStageWords(10) + kEncGuardSlackWords &&
               encGuardLimit(11, 120) + 256u <= encStageWords(11) + kEncGuardSlackWords, "");
-template <int P, uint32_t FT, bool kFull, bool kSpill, bool kGuard = false>
+// kPool (with kSpill): the slot comes from `pool` at the first flush instead of being `spill` (see SpillPool).
+template <int P, uint32_t FT, bool kFull, bool kSpill, bool kGuard = false, bool kPool = false>
 __device__ __forceinline__ uint32_t encodeRows(
     const ChunkSource<FT>& src,
     uint32_t n,                           // symbols in this half's block (0 = idle half)
@@ -376,10 +423,12 @@ __device__ __forceinline__ uint32_t encodeRows(
     uint8_t* __restrict__ ring,           // LDS, this half's 512-byte symbol ring
     uint32_t hl,
     bool upper,
-    uint16_t* __restrict__ spill,         // this half's spill slot (kSpill only)
+    uint16_t* spill,                      // this half's spill slot (kSpill only; kPool: located at the first flush)
     uint32_t& spilledOut,                 // words flushed to it (multiple of 8)
     uint32_t& stateOut,
-    bool& overrunOut) {
+    bool& overrunOut,
+    SpillPool* pool = nullptr) {
+  static_assert(!kPool || kSpill, "");
   const uint32_t laneMaskLt = (1u << hl) - 1u;
   uint32_t state = kStartState;
   uint32_t outOff = 0;
@@ -402,10 +451,15 @@ __device__ __forceinline__ uint32_t encodeRows(
       nvec = 0;
       overrun = true;
     }
+    if constexpr (kPool) {
+      if (pool->pair == kNoSpillPair) pool->pair = spillAcquire(*pool, blockIdx.x);  // wave-uniform
+      spill = pool->base + ((size_t)pool->pair * 2u + (upper ? 1u : 0u)) * encSpillSlotWords(P);
+    }
     uint4* dst = (uint4*)(spill + spilled);
     for (uint32_t i = hl; i < nvec; i += 32u) {
       const u32x4e v = *(const LdsU4e*)(uintptr_t)(stageBase + 16u * i);
-      dst[i] = make_uint4(v.x, v.y, v.z, v.w);
+      if constexpr (kPool) coherentStore16(&dst[i], make_uint4(v.x, v.y, v.z, v.w));
+      else dst[i] = make_uint4(v.x, v.y, v.z, v.w);
     }
     const uint32_t rem = outOff & 7u;
     uint16_t t = 0;

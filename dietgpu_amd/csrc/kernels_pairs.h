@@ -162,7 +162,10 @@ __host__ __device__ constexpr uint32_t encPairLdsBytes(int P, bool spill, uint32
   return 2u * 4096u + 2u * encPairStageWords(P, spill, ft) * 2u + 2u * 512u;
 }
 
-// Persistent: workgroup w encodes the pairs w, w + G, ...; a.spill holds [gridDim.x][2][encSpillSlotWords(P)].
+// grid = one workgroup (one wavefront) per pair of elements: the hardware dispatches them as slots free up, which
+// balances the kernel's serial phases far better than persistent workgroups that own 5 or 6 pairs each (32768 x 4 Ki
+// bf16: 133.7 -> 95.7 us, profiles/r05_ab_pair_encoder_hw_dispatch.txt).  Spill slots (kSpill) come from a.spill as a
+// POOL handed out through a.spillFlags (SpillPool, kernels_encode.h).  The loop form also serves a smaller grid.
 // The host guarantees size(b) <= 4096 for every element (encTileBlocksFor).
 template <int P, uint32_t FT, bool kSpill>
 __global__ __launch_bounds__(64) void k_ans_encode_pair(EncodeArgs a) {
@@ -178,7 +181,11 @@ __global__ __launch_bounds__(64) void k_ans_encode_pair(EncodeArgs a) {
   uint8_t* ring = smem + 8192u + 4u * kCap + half * 512u;
   const uint32_t tableLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)sTable;
   const uint32_t stageLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)stage;
-  uint16_t* spillSlot = kSpill ? a.spill + ((size_t)blockIdx.x * 2u + half) * encSpillSlotWords(P) : nullptr;
+  SpillPool pool;
+  pool.base = a.spill;
+  pool.flags = a.spillFlags;
+  pool.pairs = a.spillPairs;
+  pool.pair = kNoSpillPair;
 
   const uint32_t B = a.numInBatch;
   const uint32_t numPairs = (B + 1u) >> 1;
@@ -252,12 +259,12 @@ __global__ __launch_bounds__(64) void k_ans_encode_pair(EncodeArgs a) {
     uint32_t spilled = 0;
     bool overrun = false;  // see encodeRows: only with a caller-supplied histogram that does not cover the data
     if (bothFull) {
-      words = encodeRows<P, FT, true, kSpill, !kSpill>(src, n, kRowsPerBlock, tableLds, stageLds, ring, hl, upper, spillSlot, spilled,
-                                              state, overrun);
+      words = encodeRows<P, FT, true, kSpill, !kSpill, kSpill>(src, n, kRowsPerBlock, tableLds, stageLds, ring, hl, upper, nullptr,
+                                                        spilled, state, overrun, &pool);
     } else {
       const uint32_t nMax = sLo > sHi ? sLo : sHi;
-      words = encodeRows<P, FT, false, kSpill, !kSpill>(src, n, divUp(nMax, 32u), tableLds, stageLds, nullptr, hl, upper, spillSlot,
-                                               spilled, state, overrun);
+      words = encodeRows<P, FT, false, kSpill, !kSpill, kSpill>(src, n, divUp(nMax, 32u), tableLds, stageLds, nullptr, hl, upper,
+                                                         nullptr, spilled, state, overrun, &pool);
     }
     pairLdsFence();  // stage complete
 
@@ -283,17 +290,18 @@ __global__ __launch_bounds__(64) void k_ans_encode_pair(EncodeArgs a) {
     if (have) {
       uint4* dst = (uint4*)(ans + ansOverhead(1u));
       if (kSpill && spilled) {
-        // spilled vectors first (written by this wave; its stores must have been performed)
+        // spilled vectors first (written by this wave through agent-scope stores; they must have been performed)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint4* sp = (const uint4*)spillSlot;
+        const uint4* sp = (const uint4*)(pool.base + ((size_t)pool.pair * 2u + half) * encSpillSlotWords(P));
         const uint32_t sv = spilled / kBlockAlignWords;
-        for (uint32_t i = hl; i < sv; i += 32u) streamStore<kNtEncStores>(&dst[i], sp[i]);
+        for (uint32_t i = hl; i < sv; i += 32u) streamStore<kNtEncStores>(&dst[i], coherentLoad16(&sp[i]));
         dst += sv;
       }
       const uint32_t vecs = roundUp(words, kBlockAlignWords) / kBlockAlignWords;
       const uint4* s4 = (const uint4*)stage;
       for (uint32_t i = hl; i < vecs; i += 32u) streamStore<kNtEncStores>(&dst[i], s4[i]);
     }
+    if (kSpill && pool.pair != kNoSpillPair) spillRelease(pool);  // wave-uniform
     pairLdsFence();  // the next pair overwrites tables and stages
   }
 }
