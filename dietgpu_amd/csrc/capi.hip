@@ -847,7 +847,9 @@ int launchEncodePFD(const EncodeArgs& a, uint32_t tileBlocks, uint32_t grid, hip
     DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT, kSpill, kBlocksPerSmallTile, kPersistent>), dim3(grid), dim3(kBlocksPerSmallTile * 32),
                 encLdsBytes(P, kSpill, FT, kBlocksPerSmallTile), stream, a);
   } else {
-    DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT, kSpill, kBlocksPerTile, kPersistent>), dim3(grid), dim3(kBlocksPerTile * 32),
+    // (8-block float tiles exist in the persistent form only: encoderHardwareDispatch never asks for the other)
+    constexpr bool kPers = kPersistent || kSpill;
+    DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT, kSpill, kBlocksPerTile, kPers>), dim3(grid), dim3(kBlocksPerTile * 32),
                 encLdsBytes(P, kSpill, FT, kBlocksPerTile), stream, a);
   }
   DGPU_HIP(hipGetLastError());
@@ -862,9 +864,7 @@ int launchEncodePF(const EncodeArgs& a, uint32_t tileBlocks, uint32_t grid, bool
     DGPU_HIP(hipGetLastError());
     return DGPU_OK;
   }
-  if constexpr (!kSpill) {
-    if (hwDispatch) return launchEncodePFD<P, FT, false>(a, tileBlocks, grid, stream);
-  }
+  if (hwDispatch) return launchEncodePFD<P, FT, false>(a, tileBlocks, grid, stream);
   return launchEncodePFD<P, FT, true>(a, tileBlocks, grid, stream);
 }
 
@@ -916,20 +916,22 @@ uint32_t tilesFor(uint32_t maxSize) { return divUp(divUp(maxSize, kBlockSize), e
 
 uint32_t absentWorkgroupModulo();  // test hook, defined with the C ABI below
 
-// How the workgroups of the tiled RAW-BYTE encoder come to their tiles: -1 = the library decides, 0 = persistent
-// workgroups with a static ticket map, 1 = one workgroup per tile, dispatched by the hardware
-// (dgpu_debug_set_encoder_dispatch; DGPU_ENC_DISPATCH in the environment sets the initial value, for A/B runs).
-// Measured on MI355X (profiles/r05_ab_encoder_hw_dispatch.txt): 256 x 1 MiB Zipf bytes 152.7 -> 141.5 us -- 8192 tiles
-// on 768 resident workgroups (3 per CU) are 10.67 rounds, and the compute-bound row loop of a slow CU no longer holds
-// a fixed share of them.  The float encoders (6 workgroups per CU, memory-bound) gain nothing on 256 x 512 Ki and lose
-// 1-3 % on few large tensors, and a hardware-dispatched grid has no natural owner for their spill slots: they stay
-// persistent (the variant with a spill-slot pool: tools/experiments/encoder_hardware_dispatch_for_floats.patch).
+// How the workgroups of the tiled encoder come to their tiles: persistent workgroups with a static ticket map, or one
+// workgroup per tile, dispatched by the hardware in ticket order.  Measured on MI355X
+// (profiles/r05_ab_encoder_hw_dispatch.txt, r05_ab_small_tiles_hw_dispatch.txt, r05_ab_pair_encoder_hw_dispatch.txt):
+//   * raw bytes, 256 x 1 MiB: 152.7 -> 141.5 us under hardware dispatch (8192 tiles on 768 resident workgroups: the
+//     compute-bound row loop of a slow CU no longer holds a fixed share of them);
+//   * float tiles of 2 / 4 blocks (batches of elements of <= 16 Ki words): 118 -> 96 us / 98 -> 88 us;
+//   * 8-block float tiles: nothing on 256 x 512 Ki, 1-3 % slower on few large tensors: they stay persistent;
+//   * k_ans_encode_pair (single-block elements) always runs one workgroup per pair: 133.7 -> 96.8 us.
+// -1 = this policy; dgpu_debug_set_encoder_dispatch / DGPU_ENC_DISPATCH force 0 (persistent) or 1 (hardware) where the
+// kernel exists in both forms (tests, A/B runs).
 std::atomic<int> g_encDispatch{[] {
   const char* e = getenv("DGPU_ENC_DISPATCH");
   return e && *e ? atoi(e) : -1;
 }()};
-bool encoderHardwareDispatch(uint32_t numTickets, uint32_t resident, uint32_t floatType) {
-  if (encodeSpills(floatType)) return false;
+bool encoderHardwareDispatch(uint32_t numTickets, uint32_t resident, uint32_t floatType, uint32_t tileBlocks) {
+  if (encodeSpills(floatType) && tileBlocks >= kBlocksPerTile) return false;  // (no hardware-dispatched build of those)
   const int m = g_encDispatch.load();
   if (m >= 0) return m != 0;
   return numTickets > resident;  // more tiles than slots: let the hardware balance them
@@ -1029,7 +1031,7 @@ int encodeCommon(
   // k_ans_encode_pair is always persistent.  Spill slots (float inputs, persistent): [resident][slots per workgroup].
   const uint32_t numTickets = B * maxTiles;
   const uint32_t resident = maxTiles > 0 ? encodeGrid(P, floatType, tileBlocks, numTickets) : 0u;
-  const bool hwDispatch = tileBlocks != kBlocksPerSingleTile && encoderHardwareDispatch(numTickets, resident, floatType);
+  const bool hwDispatch = tileBlocks != kBlocksPerSingleTile && encoderHardwareDispatch(numTickets, resident, floatType, tileBlocks);
   uint16_t* spill = nullptr;
   uint32_t* spillFlags = nullptr;
   uint32_t spillPairs = 0;
@@ -1038,13 +1040,13 @@ int encodeCommon(
     const uint32_t slotsPerWg = tileBlocks == kBlocksPerSingleTile ? 2u : tileBlocks;
     DGPU_ALLOC(sp, uint16_t, arena, (size_t)resident * slotsPerWg * encSpillSlotWords(P));
     spill = sp;
-    if (tileBlocks == kBlocksPerSingleTile) {
-      // k_ans_encode_pair runs one workgroup per pair: its slots are a pool of `resident` pairs, handed out through
-      // library-owned flags that are zero at rest
+    if (tileBlocks == kBlocksPerSingleTile || hwDispatch) {
+      // one workgroup per pair / tile: the slots are a POOL with a pair for every wavefront that can be resident,
+      // handed out through library-owned flags that are zero at rest
       uint32_t *arrive = nullptr, *acc = nullptr;
       int rc = arrivalCounters(lease, &arrive, &acc, &spillFlags);
       if (rc) return rc;
-      spillPairs = resident;
+      spillPairs = resident * slotsPerWg / 2u;
       DGPU_REQUIRE(spillPairs <= kCounterWordsSpill, "more resident encoder wavefronts than spill-pool flags");
     }
   }

@@ -605,11 +605,14 @@ __device__ __forceinline__ uint32_t encodeRows(
 // unfinished ones never waits, so there is no deadlock at any residency.
 // With the whole grid resident nobody steals and this IS the static schedule.
 //
-// kPersistent = false (raw bytes only, capi.hip encoderHardwareDispatch): the same kernel launched with one workgroup
-// per ticket -- the hardware dispatches workgroups in index order as slots free up, so a slow CU simply takes fewer
-// tiles (256 x 1 MiB Zipf bytes: 152.7 -> 141.5 us).  The claim words stay: a workgroup still makes sure its element's
-// previous tile is claimed and encodes it first if it is not, so nothing depends on the dispatch order.  The float
-// kernels need per-workgroup spill slots, which only a persistent grid can index by blockIdx.x.
+// kPersistent = false (capi.hip encoderHardwareDispatch): the same kernel launched with one workgroup per ticket -- the
+// hardware dispatches workgroups in index order as slots free up, so a slow CU simply takes fewer tiles.  Raw bytes
+// (256 x 1 MiB Zipf bytes: 152.7 -> 141.5 us) and float tiles of 2 or 4 blocks (16384 x 8 Ki bf16: 118 -> 96 us,
+// 8192 x 16 Ki: 98 -> 88 us) run this way; 8-block float tiles gain nothing and stay persistent
+// (profiles/r05_ab_encoder_hw_dispatch.txt, r05_ab_small_tiles_hw_dispatch.txt).  The claim words stay: a workgroup
+// still makes sure its element's previous tile is claimed and encodes it first if it is not, so nothing depends on the
+// dispatch order.  Float kernels spill to a slot: a persistent workgroup indexes its own by blockIdx.x, a
+// hardware-dispatched one takes a pair from a pool (SpillPool).
 //
 // Tile descriptors carry {status:2, ..., failed:1 (bit 40), words:32}: the padded word count of a tile (aggregate) or
 // of all tiles up to it (inclusive), and a sticky flag set by a tile that overran its stage (caller-supplied
@@ -639,8 +642,16 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
   uint16_t* stage = sStage + hw * kCap;
   const uint32_t stageLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)stage;
   const uint32_t tableLds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)sTable;
-  static_assert(kPersistent || !kSpill, "a hardware-dispatched grid has no spill slots: blockIdx.x does not bound what is resident");
-  uint16_t* spillSlot = kSpill ? a.spill + ((size_t)blockIdx.x * kTB + hw) * encSpillSlotWords(P) : nullptr;
+  // Spill slots (kSpill): a persistent workgroup owns kTB of them; under hardware dispatch (tiles of 2 or 4 blocks)
+  // blockIdx.x does not bound what is resident and a wavefront takes a pair from the pool when it has to (SpillPool)
+  constexpr bool kPool = kSpill && !kPersistent;
+  static_assert(!kPool || kTB < kBlocksPerTile, "8-block float tiles run persistent (hardware dispatch measured no gain there)");
+  uint16_t* spillSlot = (kSpill && !kPool) ? a.spill + ((size_t)blockIdx.x * kTB + hw) * encSpillSlotWords(P) : nullptr;
+  SpillPool pool;
+  pool.base = a.spill;
+  pool.flags = a.spillFlags;
+  pool.pairs = a.spillPairs;
+  pool.pair = kNoSpillPair;
 
   if (a.absentModulo && blockIdx.x % a.absentModulo == 1u) {
     // test hook: a workgroup that becomes resident late (~0.5 ms after the others)
@@ -752,8 +763,8 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
       uint32_t spilled = 0;  // words already in the spill slot
       bool overrun = false;
       if (waveFull || waveHalf) {
-        words = encodeRows<P, FT, true, kSpill>(src, n, kRowsPerBlock, tableLds, stageLds, sRing + hw * 512u, hl, upper,
-                                                spillSlot, spilled, state, overrun);
+        words = encodeRows<P, FT, true, kSpill, false, kPool>(src, n, kRowsPerBlock, tableLds, stageLds, sRing + hw * 512u, hl, upper,
+                                                              spillSlot, spilled, state, overrun, &pool);
       } else {
         // rows needed by the larger of the two halves (uniform)
         uint32_t nA = 0;
@@ -761,8 +772,8 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
           uint32_t beginA = firstBlockOfWave * kBlockSize;
           nA = size - beginA < kBlockSize ? size - beginA : kBlockSize;  // first half is never smaller than the second
         }
-        words = encodeRows<P, FT, false, kSpill>(src, n, divUp(nA, 32u), tableLds, stageLds, nullptr, hl, upper, spillSlot,
-                                                 spilled, state, overrun);
+        words = encodeRows<P, FT, false, kSpill, false, kPool>(src, n, divUp(nA, 32u), tableLds, stageLds, nullptr, hl, upper, spillSlot,
+                                                               spilled, state, overrun, &pool);
       }
 
       if (haveBlock) {
@@ -849,10 +860,10 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
         if (kSpill && spilled) {
           // spilled vectors first (written by this wave; its stores must have been performed)
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          const uint4* sp = (const uint4*)spillSlot;
+          const uint4* sp = (const uint4*)(kPool ? pool.base + ((size_t)pool.pair * 2u + (upper ? 1u : 0u)) * encSpillSlotWords(P) : spillSlot);
           uint32_t sv = spilled / kBlockAlignWords;
           const uint32_t svFit = sv < fit ? sv : fit;
-          for (uint32_t i = hl; i < svFit; i += 32u) streamStore<kNtEncStores>(&dst[i], sp[i]);
+          for (uint32_t i = hl; i < svFit; i += 32u) streamStore<kNtEncStores>(&dst[i], kPool ? coherentLoad16(&sp[i]) : sp[i]);
           dst += sv;
           fit -= svFit;
         }
@@ -861,6 +872,7 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
         const uint4* s4 = (const uint4*)stage;
         for (uint32_t i = hl; i < vecs; i += 32u) streamStore<kNtEncStores>(&dst[i], s4[i]);
       }
+      if (kPool && pool.pair != kNoSpillPair) spillRelease(pool);  // wave-uniform
     }  // tiles [tileLo, tile0] of element b
   }
 }

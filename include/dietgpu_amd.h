@@ -322,11 +322,12 @@ int dgpu_prof_summary(char* buf, size_t cap);
  * running workgroups take over the tiles of workgroups that have not started. */
 void dgpu_debug_set_absent_workgroups(uint32_t modulo);
 
-/* Measurement / test hook: how the workgroups of the tiled RAW-BYTE encoder (k_ans_encode<.., FT = 0, ..>; replaces the
- * grid of ansEncodeBatch, GpuANSEncode.cuh:429-461) come to their tiles.  -1 (default): the library decides per call
- * (one workgroup per tile when there are more tiles than resident workgroups); 0: as many persistent workgroups as fit
- * on the device, static ticket map; 1: one workgroup per tile, dispatched by the hardware in ticket order.  Archives
- * are byte-identical either way.  The float encoders always run persistent. */
+/* Measurement / test hook: how the workgroups of the tiled encoder (k_ans_encode; replaces the grid of ansEncodeBatch,
+ * GpuANSEncode.cuh:429-461) come to their tiles -- for raw bytes and for float tiles of 2 or 4 blocks, the kernels that
+ * exist in both forms.  -1 (default): the library decides per call (one workgroup per tile when there are more tiles
+ * than resident workgroups); 0: as many persistent workgroups as fit on the device, static ticket map; 1: one workgroup
+ * per tile, dispatched by the hardware in ticket order.  Archives are byte-identical either way.  8-block float tiles
+ * always run persistent, single-block elements always one workgroup per pair. */
 void dgpu_debug_set_encoder_dispatch(int mode);
 
 /* Measurement / test hook: the order in which the workgroups of the tiled decoder (k_ans_decode; replaces the grid of

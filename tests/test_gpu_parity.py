@@ -1649,11 +1649,11 @@ def test_capped_stride_compress_and_bounded_stride_decompress(dg, ft):
 # ----------------------------------------------------------------- encoder dispatch modes
 @pytest.mark.parametrize("mode", [0, 1])
 def test_encoder_dispatch_modes(dg, mode):
-    # The tiled raw-byte encoder runs either as persistent workgroups with a static ticket map (0) or as one workgroup
-    # per tile dispatched by the hardware (1); the library picks per call (more tiles than resident workgroups: 1), this
-    # hook forces one.  Archives are byte-identical to the oracle either way: late workgroups and the take-over of
-    # their tiles, look-back chains over 1027 tiles, ragged batches, BASELINE config 2.  (The float encoders are
-    # always persistent: the calls below that use them run unchanged.)
+    # The tiled encoder runs either as persistent workgroups with a static ticket map (0) or as one workgroup per tile
+    # dispatched by the hardware (1) -- raw bytes and float tiles of 2 / 4 blocks; the library picks per call (more
+    # tiles than resident workgroups: 1), this hook forces one.  Archives are byte-identical to the oracle either way:
+    # late workgroups and the take-over of their tiles, look-back chains over 1027 tiles, ragged batches, BASELINE
+    # config 2, small float elements with spilling members.  (8-block float tiles are always persistent.)
     L = dg.lib()
     L.dgpu_debug_set_encoder_dispatch(mode)
     try:
@@ -1663,6 +1663,8 @@ def test_encoder_dispatch_modes(dg, mode):
         test_fuzz_ragged_batches(dg, 1)
         test_fuzz_ragged_batches(dg, 4)
         test_baseline_config2_zipf_bytes(dg)
+        test_ragged_batches_of_small_elements(dg, 10, 2)  # float tiles of 2 / 4 blocks: both forms exist
+        test_ragged_batches_of_small_elements(dg, 11, 4)
     finally:
         L.dgpu_debug_set_encoder_dispatch(-1)
 
@@ -1702,21 +1704,23 @@ def test_decoder_workgroup_orders(dg, order):
         L.dgpu_debug_set_decoder_order(-1)
 
 
-@pytest.mark.parametrize("ft,prob_bits", [(O.BFLOAT16, 10), (O.FLOAT16, 11), (O.FLOAT32, 9)])
-def test_single_block_elements_with_more_spilling_pairs_than_pool_slots(dg, ft, prob_bits):
-    # k_ans_encode_pair runs one workgroup per pair of elements and takes its spill slots from a pool sized for the
-    # wavefronts that can be resident (a few thousand pairs), handed out through library-owned flags.  20000 single-block
-    # elements of random bit patterns make EVERY pair spill: many more spilling pairs than slots, slots changing hands
-    # between XCDs.  Archives byte-identical to the oracle, round trip exact, and a second call (the flags are zero at
-    # rest) gives the same archives.
+@pytest.mark.parametrize("ft,prob_bits,blocks", [(O.BFLOAT16, 10, 1), (O.FLOAT16, 11, 1), (O.FLOAT32, 9, 1),
+                                                 (O.BFLOAT16, 10, 2), (O.FLOAT16, 11, 4), (O.FLOAT32, 10, 2)])
+def test_small_elements_with_more_spilling_wavefronts_than_pool_slots(dg, ft, prob_bits, blocks):
+    # The float encoders of small elements -- k_ans_encode_pair (single-block elements) and k_ans_encode with tiles of 2
+    # or 4 blocks -- run one workgroup per pair / tile and take their spill slots from a pool sized for the wavefronts
+    # that can be resident (a few thousand pairs of slots), handed out through library-owned flags.  Thousands of
+    # elements of random bit patterns make EVERY wavefront spill: many more spilling wavefronts than slots, slots
+    # changing hands between XCDs.  Archives byte-identical to the oracle, round trip exact, and a second call (the
+    # flags are zero at rest) gives the same archives.
     if getattr(dg, "name", "") == "torch_ops":
         dg._p10(prob_bits)
-    rng = np.random.default_rng(2100 + ft)
+    rng = np.random.default_rng(2100 + ft + 10 * blocks)
     dt = np.uint32 if ft == O.FLOAT32 else np.uint16
     hi = 1 << (32 if ft == O.FLOAT32 else 16)
-    B = 20000
-    ns = rng.integers(3900, 4097, B)
-    ns[::7] = 4096
+    B = 20000 // blocks
+    ns = rng.integers(blocks * 4096 - 196, blocks * 4096 + 1, B)
+    ns[::7] = blocks * 4096
     flat = rng.integers(0, hi, int(ns.sum()), dtype=np.uint64).astype(dt)
     splits = torch.from_numpy(ns.astype(np.int32))
     t = words_to_tensor(ft, flat)
