@@ -3,14 +3,14 @@
 # kernel stats of the headline loop alone and of the one-buffer-set loop alone, PMC passes (+ the traffic file stamped
 # with the kernel source hash), timeline, microbenchmarks.
 # Usage: gpurun --timeout 2700 -- bash tools/gpu_final.sh <tag>      (outputs under gpurun_out/; tools/collect_profiles.sh <tag> copies them)
-T=${1:-r04}
+T=${1:-r05}
 mkdir -p gpurun_out
-( timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -8 ) > gpurun_out/${T}_pytest.txt
+( timeout 1500 python -m pytest tests -m gpu -q -n 4 2>&1 | tail -8 ) > gpurun_out/${T}_pytest.txt
 tail -3 gpurun_out/${T}_pytest.txt
 python bench.py > gpurun_out/${T}_bench_bf16.json 2>/dev/null
 python bench.py --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/${T}_bench_bf16_driver_protocol.json 2>/dev/null
 for w in u8 fp16 fp32; do python bench.py --no-cpu-baseline --steps 200 --warmup 20 --workload $w > gpurun_out/${T}_bench_$w.json 2>/dev/null; done
-for s in "8192 16384" "32768 4096" "1 134217728" "16 8388608" "2048 65536"; do set -- $s
+for s in "8192 16384" "16384 8192" "32768 4096" "1 134217728" "16 8388608" "64 2097152" "2048 65536"; do set -- $s
   python bench.py --quick --no-cpu-baseline --steps 100 --warmup 10 --batch $1 --elems $2 > gpurun_out/${T}_bench_bf16_$1x$2.json 2>/dev/null; done
 python bench.py --collective --no-cpu-baseline --chunks 1 --steps 100 --warmup 10 > gpurun_out/${T}_bench_collective_world1.json 2>/dev/null
 python bench.py --reference-protocol > gpurun_out/${T}_reference_protocol.json 2>/dev/null
