@@ -62,7 +62,7 @@ extern "C" {
 
 const char* dgpu_version(void);
 /* Bumped whenever an entry point of this header is added, removed or changes its meaning.  Code that is built
- * separately against this header (csrc/torch_ops.cpp, a cgo / JNI binding) compares the value it was compiled with
+ * separately against this header (the tensor-op library of this repository, a cgo / JNI binding) compares the value it was compiled with
  * against the library it finds at run time, so that a stale build fails at load instead of inside a call. */
 #define DGPU_ABI_VERSION 5u
 uint32_t dgpu_abi_version(void);
