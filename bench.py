@@ -442,21 +442,41 @@ def run_collective(args, data, ft, desc, world, rank, device, D):
         out, redo = plan.run(data)
         return out, dict(plan.last)
 
-    def timed(fn):
+    def timed(fn, finish=None):
         for _ in range(args.warmup):
             fn()
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             res = fn()
+        if finish:
+            res = finish()
         fence()
         return D.max_over_ranks(time.perf_counter() - t0, device) / args.steps, res
 
+    # the same exchange with the host read of step k behind the launch of step k + 1 (a plan of depth 2: two buffer
+    # sets): a steady-state step is launch-only; the result of a step is complete when its handle has been waited for
+    plan2 = D.CompressedAllGatherPlan(data, chunks=args.chunks, depth=2)
+    prev = [None]
+
+    def compressed_pipelined():
+        h = plan2.run_async(data)
+        if prev[0] is not None:
+            prev[0].wait()
+        prev[0] = h
+
+    def finish_pipelined():
+        out, redo = prev[0].wait()
+        prev[0] = None
+        return out
+
     t_plain, got_plain = timed(plain)
     t_comp, (got_comp, stats) = timed(compressed)
+    t_pipe, got_pipe = timed(compressed_pipelined, finish_pipelined)
     view = torch.int32 if ft == 3 else torch.int16
     for r in range(world):
         assert torch.equal(got_comp[r].view(view), got_plain[r].view(view)), "compressed all-gather is not bit-exact"
+        assert torch.equal(got_pipe[r].view(view), got_plain[r].view(view)), "pipelined compressed all-gather is not bit-exact"
     if rank == 0:
         recv = (world - 1) * raw_bytes if world > 1 else raw_bytes  # bytes of other ranks' tensors each rank ends up with
         print(json.dumps({
@@ -466,6 +486,7 @@ def run_collective(args, data, ft, desc, world, rank, device, D):
             "plain_all_gather_GBps_per_rank": round(recv / t_plain / 1e9, 2),
             "speedup_vs_plain": round(t_plain / t_comp, 3),
             "ms_compressed": round(t_comp * 1e3, 4),
+            "ms_compressed_pipelined": round(t_pipe * 1e3, 4),  # host read of step k behind the launch of step k + 1
             "ms_plain": round(t_plain * 1e3, 4),
             "n_gpus": world,
             "dist_backend": args.dist_backend,

@@ -321,7 +321,10 @@ class CompressedExchangePlan:
 
     HEADROOM = 1.0 / 64.0
 
-    def __init__(self, dtype, elems, rows, chunks=4, prob_bits=10, device=None, codec=None, initial_width=None):
+    def __init__(self, dtype, elems, rows, chunks=4, prob_bits=10, device=None, codec=None, initial_width=None, depth=1):
+        """`depth`: buffer sets of the plan.  1: every call ends with its one host read (all_gather / all_to_all).  2: a
+        step can be ENQUEUED (all_gather_async) while the previous one is still unchecked, so that the host read of step
+        k (ExchangeHandle.wait) happens behind the launch of step k + 1 and a steady-state step is launch-only."""
         self.world = dist.get_world_size()
         self.dev = torch.device(device) if device is not None else torch.device("cpu")
         self.on_gpu = self.dev.type == "cuda"
@@ -332,14 +335,19 @@ class CompressedExchangePlan:
         self.chunks = max(1, min(chunks, rows))
         self.bounds = [shard_range(rows, k, self.chunks) for k in range(self.chunks)]
         u8 = dict(dtype=torch.uint8, device=self.dev)
-        # send / receive matrices are flat and sized for the worst case; a step uses the first rows x width bytes
-        self.send = torch.empty((rows * self.cap,), **u8)
-        self.recv = torch.empty((self.world * rows * self.cap,), **u8)
-        self.sizes = torch.zeros((rows,), dtype=torch.int32, device=self.dev)
-        self.status = torch.zeros((self.world, rows), **u8)
-        self.stat = torch.zeros((2,), dtype=torch.int32, device=self.dev)  # {largest archive of all ranks, rows decoded}
-        self._max_work = None
-        self.out = None
+        # send / receive matrices are flat and sized for the worst case; a step uses the first rows x width bytes.
+        # `depth` sets of them; the attributes below (send, recv, sizes, status, stat, out) always name the set of the step
+        # that is being enqueued or finished (_bind)
+        self._slots = [{
+            "send": torch.empty((rows * self.cap,), **u8),
+            "recv": torch.empty((self.world * rows * self.cap,), **u8),
+            "sizes": torch.zeros((rows,), dtype=torch.int32, device=self.dev),
+            "status": torch.zeros((self.world, rows), **u8),
+            "stat": torch.zeros((2,), dtype=torch.int32, device=self.dev),  # {largest archive of all ranks, rows decoded}
+            "max_work": None, "out": None, "pending": None,
+        } for _ in range(max(1, int(depth)))]
+        self._cur = 0
+        self._bind(self._slots[0])
         self.width = None if initial_width is None else self._round_width(initial_width)
         self._width_agreed = initial_width is None  # widths derived from all-reduced sizes agree by construction
         self.comp_stream = torch.cuda.Stream(self.dev) if self.on_gpu else None
@@ -347,6 +355,24 @@ class CompressedExchangePlan:
         self.last = {}
 
     # ---- helpers
+    def _bind(self, slot):
+        self._slot = slot
+        self.send, self.recv, self.sizes, self.status, self.stat = slot["send"], slot["recv"], slot["sizes"], slot["status"], slot["stat"]
+        self._max_work, self.out = slot["max_work"], slot["out"]
+
+    def _unbind(self):
+        self._slot["max_work"], self._slot["out"] = self._max_work, self.out
+
+    def _next_slot(self):
+        """The buffer set of the step about to be enqueued; its previous step must have been waited for."""
+        self._unbind()
+        self._cur = (self._cur + 1) % len(self._slots)
+        slot = self._slots[self._cur]
+        if slot["pending"] is not None:
+            slot["pending"].wait()  # (a caller that never waits: the step that used these buffers is finished first)
+        self._bind(slot)
+        return slot
+
     def _round_width(self, nbytes):
         w = (int(nbytes) + 15) // 16 * 16
         return max(min(w, self.cap), min(self.codec.min_width, self.cap))
@@ -385,20 +411,36 @@ class CompressedExchangePlan:
         torch.amax(self.sizes, dim=0, keepdim=True, out=self.stat[0:1])
         self._max_work = dist.all_reduce(self.stat[0:1], op=dist.ReduceOp.MAX, async_op=True) if self.world > 1 else None
 
-    def _finish(self, kind, fallback, statuses_differ_between_ranks):
-        """The ONE device-to-host read of a step: {largest archive over all ranks, rows that decoded}."""
+    def _post_decode(self):
+        """The device side of a step's check, enqueued with the step (on the caller's stream, behind the decode stream):
+        rows that decoded, agreed over the ranks -- the fall-back is a collective, every rank must agree on whether it
+        runs (in the all-to-all only sender and receiver see a row's status; in the all-gather a local decode rejection
+        must not desynchronise the ranks) -- and both statistics on their way to pinned host memory."""
         torch.sum(self.status.view(-1), dim=0, keepdim=True, dtype=torch.int32, out=self.stat[1:2])
-        if statuses_differ_between_ranks and self.world > 1:
-            # the fall-back is a collective: every rank must agree on whether it runs (in the all-to-all only sender
-            # and receiver see a given row's status; in the all-gather a local decode rejection must not desynchronise
-            # the ranks)
+        if self.world > 1:
             dist.all_reduce(self.stat[1:2], op=dist.ReduceOp.MIN)
         if self._max_work is not None:
             self._max_work.wait()
             self._max_work = None
-        largest, decoded = (int(v) for v in self.stat.tolist())
+        slot = self._slot
+        slot["width"] = self.width
+        if self.on_gpu:
+            if slot.get("host") is None:
+                slot["host"] = torch.empty((2,), dtype=torch.int32).pin_memory()
+                slot["event"] = torch.cuda.Event()
+            slot["host"].copy_(self.stat, non_blocking=True)
+            slot["event"].record()
+
+    def _finish(self, kind, fallback):
+        """The ONE device-to-host read of a step: {largest archive over all ranks, rows that decoded}."""
+        slot = self._slot
+        if self.on_gpu:
+            slot["event"].synchronize()
+            largest, decoded = (int(v) for v in slot["host"].tolist())
+        else:
+            largest, decoded = (int(v) for v in self.stat.tolist())
         failed = self.status.numel() - decoded
-        used_width = self.width
+        used_width = slot["width"]
         redo = fallback() if failed else 0
         self.last = {"kind": kind, "width": used_width, "largest_archive": largest, "rows_sent_uncompressed": redo,
                      "wire_bytes": self.rows * used_width + redo * self.row_bytes, "raw_bytes": self.rows * self.row_bytes}
@@ -406,10 +448,25 @@ class CompressedExchangePlan:
         self.width = self._round_width(largest * (1.0 + self.HEADROOM) + 64)
         return redo
 
+    def _handle(self, kind, fallback):
+        self._post_decode()
+        self._unbind()
+        h = ExchangeHandle(self, self._slot, kind, fallback)
+        self._slot["pending"] = h
+        return h
+
     # ---- all-gather
     def all_gather(self, shard):
         """shard [rows, elems] -> (gathered [world, rows, elems], rows that had to be sent uncompressed)."""
+        return self.all_gather_async(shard).wait()
+
+    def all_gather_async(self, shard):
+        """Enqueues the step and returns an ExchangeHandle WITHOUT reading anything back: `handle.wait()` -> (gathered,
+        rows sent uncompressed) does the step's one host read and, if rows did not fit the exchange width, their
+        uncompressed fall-back.  The output is complete only after wait(); `shard` must stay unchanged until then.  With
+        a plan of depth 2 the wait of step k belongs behind the call that enqueues step k + 1."""
         assert shard.shape == (self.rows, self.elems) and shard.dtype == self.dtype and shard.is_contiguous()
+        self._next_slot()
         if self.out is None or self.out.shape[0] != self.world or self.out.dim() != 3:
             self.out = torch.empty((self.world, self.rows, self.elems), dtype=self.dtype, device=self.dev)
         if self.width is None:
@@ -441,12 +498,14 @@ class CompressedExchangePlan:
             cur.wait_stream(self.comp_stream)
             cur.wait_stream(self.dec_stream)
 
+        status_of_step, out_of_step = self.status, self.out
+
         def fallback():
             # per ROW: the rows that failed are gathered again uncompressed, padded to the largest count of any rank.
             # Every rank decoded the same archives, so the status matrices SHOULD be equal -- but the fall-back is a
             # collective whose shapes derive from them, so they are made equal (a row is bad if ANY rank could not
             # decode it: MIN over ranks of a world x rows byte matrix) rather than assumed to be.
-            agreed = self.status.to(torch.int32)
+            agreed = status_of_step.to(torch.int32)
             if world > 1:
                 dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
             bad = (agreed == 0)                                       # [world, rows]
@@ -461,21 +520,25 @@ class CompressedExchangePlan:
                 w.wait()
             for r in range(world):
                 idx = bad[r].nonzero().flatten()
-                self.out[r, idx] = got[r, : idx.numel()]
+                out_of_step[r, idx] = got[r, : idx.numel()]
             return counts[dist.get_rank()]
 
         # (the count of decoded rows is all-reduced too: every rank must agree on WHETHER the fall-back collective runs)
-        redo = self._finish("all_gather", fallback, True)
-        return self.out, redo
+        return self._handle("all_gather", fallback)
 
     # ---- all-to-all
     def all_to_all(self, send):
         """send [world, m, elems] (row block j goes to rank j) -> (received [world, m, elems] (block i came from rank i),
         rows of this rank's receive side that had to be sent uncompressed)."""
+        return self.all_to_all_async(send).wait()
+
+    def all_to_all_async(self, send):
+        """all_to_all without the host read: see all_gather_async."""
         world = self.world
         assert send.dim() == 3 and send.shape[0] == world and send.shape[2] == self.elems and send.is_contiguous()
         m = send.shape[1]
         assert world * m == self.rows and send.dtype == self.dtype
+        self._next_slot()
         if self.out is None or self.out.shape != send.shape:
             self.out = torch.empty_like(send)
         flat = send.view(world * m, self.elems)
@@ -515,6 +578,7 @@ class CompressedExchangePlan:
             cur.wait_stream(self.dec_stream)
         if world * m < self.status.numel():
             self.status.view(-1)[world * m :] = 1
+        out_of_step = self.out
 
         def fallback():
             # per ROW.  Only sender and receiver know which rows failed: the receiver tells every sender (a tiny
@@ -532,11 +596,34 @@ class CompressedExchangePlan:
             pack = send[bad_send]                                         # rows ordered by destination
             got = torch.empty((sum(out_split), self.elems), dtype=self.dtype, device=self.dev)
             dist.all_to_all_single(got, pack.contiguous(), out_split, in_split)
-            self.out[bad_recv] = got
+            out_of_step[bad_recv] = got
             return sum(out_split)
 
-        redo = self._finish("all_to_all", fallback, True)
-        return self.out, redo
+        return self._handle("all_to_all", fallback)
+
+
+class ExchangeHandle:
+    """A step of a CompressedExchangePlan that has been enqueued but not checked.  wait() -> (output, rows that had to be
+    sent uncompressed): the step's ONE device-to-host read (largest archive of all ranks, rows that decoded), the per-row
+    uncompressed fall-back if rows did not fit, and the width of the next step."""
+
+    def __init__(self, plan, slot, kind, fallback):
+        self.plan, self.slot, self.kind, self.fallback, self.result = plan, slot, kind, fallback, None
+
+    def wait(self):
+        if self.result is None:
+            p = self.plan
+            cur = p._slot
+            p._unbind()
+            p._bind(self.slot)
+            try:
+                redo = p._finish(self.kind, self.fallback)
+                self.result = (p.out, redo)
+            finally:
+                p._unbind()
+                p._bind(cur)
+            self.slot["pending"] = None
+        return self.result
 
 
 def _all_gather_flat(out_flat, in_flat, world):
@@ -559,13 +646,16 @@ def _all_to_all_flat(out_flat, in_flat, world):
 class CompressedAllGatherPlan(CompressedExchangePlan):
     """The all-gather of one [n, elems] shard (kept under its round-2 name; bench.py --collective)."""
 
-    def __init__(self, shard, chunks=4, prob_bits=10, initial_width=None, codec=None):
+    def __init__(self, shard, chunks=4, prob_bits=10, initial_width=None, codec=None, depth=1):
         assert shard.dim() == 2 and shard.is_contiguous()
         super().__init__(shard.dtype, shard.shape[1], shard.shape[0], chunks=chunks, prob_bits=prob_bits,
-                         device=shard.device, codec=codec, initial_width=initial_width)
+                         device=shard.device, codec=codec, initial_width=initial_width, depth=depth)
 
     def run(self, shard):
         return self.all_gather(shard)
+
+    def run_async(self, shard):
+        return self.all_gather_async(shard)
 
     @property
     def wire_bytes(self):

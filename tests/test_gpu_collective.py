@@ -100,6 +100,21 @@ def test_pipelined_compressed_all_gather_single_rank_rccl():
             out, redo = plan4.run(sp)
             torch.cuda.synchronize()
             assert redo == 0 and torch.equal(out[0].view(torch.int16), sp.view(torch.int16))
+        # a plan of depth 2, pipelined: nothing is read back when a step is enqueued; the wait of step k comes behind the
+        # launch of step k + 1 (different data per step: the two buffer sets must not be mixed up); the step with
+        # incompressible rows falls back at ITS wait
+        plan6 = D.CompressedAllGatherPlan(shard, chunks=2, depth=2)
+        inputs = [shard, mixed.clone(), shard.flip(0).contiguous(), shard]
+        handles = []
+        for k, x in enumerate(inputs):
+            handles.append(plan6.run_async(x))
+            if k:
+                out, redo = handles[k - 1].wait()
+                torch.cuda.synchronize()
+                assert redo == (2 if k - 1 == 1 else 0) and torch.equal(out[0].view(torch.int16), inputs[k - 1].view(torch.int16))
+        out, redo = handles[-1].wait()
+        torch.cuda.synchronize()
+        assert redo == 0 and torch.equal(out[0].view(torch.int16), shard.view(torch.int16))
         # all-to-all on the same machinery (world 1: block 0 comes back)
         plan5 = D.CompressedExchangePlan(torch.bfloat16, shard.shape[1], shard.shape[0], chunks=2, device=dev)
         got, redo = plan5.all_to_all(shard.view(1, shard.shape[0], shard.shape[1]))

@@ -253,6 +253,26 @@ def _plan_worker(rank, world, port, q):
             ok = ok and torch.equal(got[src].view(torch.int16), want.view(torch.int16))
         log.append((redo, plan2.last["width"]))
     ok = ok and log[3][0] == 0 and log[4][0] == (1 if rank == 1 else 0)
+    # a plan of depth 2, pipelined: step k is waited for BEHIND the call that enqueues step k + 1 (two buffer sets); the
+    # step with incompressible rows falls back per row at its wait, the steps around it are untouched
+    plan3 = D.CompressedExchangePlan(torch.bfloat16, elems, rows, chunks=2, device="cpu", codec=_OracleStrideCodec(O, elems), depth=2)
+    steps = ((20, {}), (21, {0: (3,)}), (22, {}), (23, {}))
+    shards = [shard_of(rank, st, nz.get(rank, ())) for st, nz in steps]
+    handles, redos = [], []
+    for k, mine in enumerate(shards):
+        handles.append(plan3.all_gather_async(mine))
+        if k >= 1:
+            out, redo = handles[k - 1].wait()
+            redos.append(redo)
+            st, nz = steps[k - 1]
+            for r in range(world):
+                ok = ok and torch.equal(out[r].view(torch.int16), shard_of(r, st, nz.get(r, ())).view(torch.int16))
+    out, redo = handles[-1].wait()
+    redos.append(redo)
+    for r in range(world):
+        ok = ok and torch.equal(out[r].view(torch.int16), shard_of(r, steps[-1][0], {}).view(torch.int16))
+    ok = ok and redos == [0, (1 if rank == 0 else 0), 0, 0] and handles[1].wait()[1] == redos[1]  # (wait is idempotent)
+    log.append(tuple(redos))
     dist.barrier()
     q.put((rank, ok, log))
     dist.destroy_process_group()
