@@ -774,7 +774,7 @@ def main():
     extras = {}
     ms = lambda seconds, steps=K: round(over_ranks(seconds) / steps * 1e3, 4)
     # (*_steady_state: the GPU's clocks take tens of milliseconds of load to settle -- the same build measured 263 us per
-    # step over 20 steps after 3 warm-up steps, 223 us in steady state, DESIGN.md section 3 -- so the same loops again
+    # step over 20 steps after 3 warm-up steps, 223 us in steady state, docs/HISTORY.md section 3 -- so the same loops again
     # behind a pre-roll of >= 400 steps.  Named extras, not the headline.)
     preroll = max(0, 400 - W)
     KS = max(K, 200)
@@ -800,7 +800,7 @@ def main():
         extras["ms_decompress_only"] = ms(timed_loop(lambda i: sets[i % rot_sets].decode(), W, K))
     if cold and not args.quick:
         # ... and the round trip with the histogram pass reading through the cache (dgpu_set_histogram_load_policy(1)):
-        # best for exactly this loop, not the default because it loses wherever only one direction runs
+        # best for exactly this loop, not the default because it loses wherever only one direction runs (docs/HISTORY.md section 3)
         codec.lib.dgpu_set_histogram_load_policy(1)
         extras["ms_per_step_cached_histogram_loads"] = ms(timed_loop(step_rot, W, K))
         extras["ms_compress_only_cached_histogram_loads"] = ms(timed_loop(lambda i: sets[i % rot_sets].encode(), W, K))

@@ -19,7 +19,7 @@
 
 // Streaming (non-temporal) access helpers and the cache policy of every stream the kernels touch.  The policies
 // were chosen on ROTATING buffers -- inputs, archives and outputs that are not in the 256 MiB memory-side cache when
-// their turn comes, as in real use -- not on a loop that re-codes one buffer set ("cache
+// their turn comes, as in real use -- not on a loop that re-codes one buffer set (docs/HISTORY.md section 3, "cache
 // policy"; profiles/r03_ab_cache_policy_*.txt, profiles/r03_rotating_phases.txt):
 //   * decoded float words are written once and not read again by the codec: non-temporal stores (1-byte
 //     non-temporal stores are slow, so decoded raw bytes use ordinary ones)

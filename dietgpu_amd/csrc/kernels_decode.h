@@ -63,7 +63,7 @@ __device__ __forceinline__ uint64_t decodeInBytes(const DecodeArgs& a, uint32_t 
 }
 
 // Workgroup index -> (element, tile) of k_ans_decode's 1-D grid of B * maxTiles workgroups (kDecOrderXcd: B rounded up to 8).  The hardware
-// dispatches workgroups in index order, workgroup w on XCD w mod 8.
+// dispatches workgroups in index order, workgroup w on XCD w mod 8 (docs/HISTORY.md section 3).
 //   kDecOrderElementMajor: w = b * T + tile -- the tiles of an element run back to back (rounds 1-4)
 //   kDecOrderTileMajor:    w = tile * B + b -- the order the encoder wrote the archives in
 //   kDecOrderXcd:          every XCD walks ITS elements (b mod 8 == XCD) element-major: consecutive workgroups touch
@@ -282,7 +282,7 @@ __host__ __device__ constexpr uint32_t decThreads(uint32_t tileBlocks) { return 
 // Store (transposition) buffers per block.  Raw bytes in 16-block tiles keep the narrow stores: a fourth
 // workgroup per CU (40 KiB instead of 48: 8 waves per SIMD) is worth more to their row loop than the 8-byte
 // stores (256 x 1 MiB Zipf bytes decode 152.5 -> 145 us).  16-bit floats are HBM-bound with the wide stores, and
-// their narrow 2-byte non-temporal stores inflate the write traffic by 1.35.
+// their narrow 2-byte non-temporal stores inflate the write traffic by 1.35 (docs/HISTORY.md section 4.2).
 __host__ __device__ constexpr uint32_t decXposeBytes(int P, uint32_t ft, uint32_t tileBlocks) {
   (void)P;
   if (ft == 0 && tileBlocks >= 16u) return 0u;

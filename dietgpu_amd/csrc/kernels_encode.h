@@ -22,7 +22,7 @@
 //   * The row step of a full block is branch-free straight-line code: the
 //     emitting lanes store their word (and, for raw bytes and bfloat16, shift
 //     their state) under the row's ballot as execution mask -- two s_mov, no
-//     branch, no select (the vector issue slots are the
+//     branch, no select (docs/HISTORY.md section 4.1: the vector issue slots are the
 //     scarce ones in this loop).
 //   * Each half-wave emits its u16 words into an LDS stage (worst case for raw
 //     bytes; 1024 words + a spill slot in temp memory for floats, see
@@ -31,15 +31,14 @@
 //     decoupled look-back over the preceding tiles of the same batch element,
 //     then copies the stage to its final place with 16-byte stores.  There is no
 //     per-block scratch buffer in HBM and no coalesce pass.
-//   * Workgroups are persistent (as many as fit on the chip) and encode tiles in
-//     TILE-MAJOR ticket order (ticket t -> element t % B, tile t / B) under a
-//     static map protected by per-tile claim words, see k_ans_encode.  A tile
-//     only ever waits on tiles that are claimed by a running workgroup: the
-//     look-back cannot deadlock whatever order the hardware dispatches
-//     workgroups in and however many of them are resident.  With a batch of B
-//     elements the predecessor started B tickets earlier, i.e. it has usually
-//     finished long before: measured with element-major order the look-back
-//     wait was 17 % of a tile's lifetime.
+//   * Tiles are encoded in TILE-MAJOR ticket order (ticket t -> element t % B, tile t / B), either by persistent
+//     workgroups (as many as fit on the chip, a static ticket map: 8-block float tiles) or by one workgroup per
+//     ticket that the hardware dispatches in index order (raw bytes, float tiles of 2 / 4 blocks), in both forms
+//     protected by per-tile claim words, see k_ans_encode.  A tile only ever waits on tiles that are claimed by a
+//     running workgroup: the look-back cannot deadlock whatever order the hardware dispatches workgroups in and
+//     however many of them are resident.  With a batch of B elements the predecessor started B tickets earlier,
+//     i.e. it has usually finished long before: measured with element-major order the look-back wait was 17 % of
+//     a tile's lifetime.
 //   * Hand-off words are single 8-byte {status, value} granules written and
 //     polled with relaxed agent-scope atomics (write-through sc1 stores /
 //     L1-bypassing loads), the placement-independent form for gfx950's
@@ -78,7 +77,7 @@ constexpr uint32_t kFlushRows = 8;
 __host__ __device__ constexpr uint32_t encSpillSlotWords(int P) { return roundUp(encStageWords(P), 8u) + 8u; }
 
 // (Raw bytes keep the worst-case stage: a 1664-word stage with spill slots -- 4 workgroups per CU -- measured -2 %
-// for 43 MiB more temp memory, and nothing once the row stored under the ballot; DESIGN.md section 5, "Config 2".)
+// for 43 MiB more temp memory, and nothing once the row stored under the ballot; docs/HISTORY.md section 5, "Config 2".)
 __host__ __device__ constexpr uint32_t encStageCap(int P, bool spill, uint32_t ft) {
   return spill ? (ft == kFloat16 ? kSpillStageWordsFp16 : kSpillStageWords) : encStageWords(P);
 }
@@ -588,7 +587,7 @@ __device__ __forceinline__ uint32_t encodeRows(
 // tickets w, w + G, w + 2G, ... (G = gridDim.x; ticket t -> element t % B, tile
 // t / B) and walks them in order: no ticket atomic on the critical path and a
 // perfectly regular round structure (a dynamic ticket counter measured 111 us, eight
-// counters 105 us, this 98 us at the time).  A plain
+// counters 105 us, this 98 us at the time; docs/HISTORY.md section 4.1).  A plain
 // static map would hang whenever part of the grid is not resident (another
 // kernel holding CUs): running workgroups would spin in the look-back on tiles
 // whose owner never starts.  Hence one claim word per tile:

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64) void k_ans_encode_pair(EncodeArgs a) {
     // element, written once and read once.  Lane hl builds the entries of symbols hl, hl + 32, ... (a row of 32
     // symbols per step: cdf = the earlier rows' total + a 32-lane scan), so that a step's 16-byte entries go to
     // CONSECUTIVE LDS addresses across the lanes -- eight consecutive symbols per lane put every lane of a half on the
-    // same four banks, 16 passes per store (the conflict k_ans_decode_pair's LUT build had).
+    // same four banks, 16 passes per store (the conflict k_ans_decode_pair's LUT build had, docs/HISTORY.md section 4.4).
     {
       const uint16_t* pdfTable = (const uint16_t*)(ans + sizeof(AnsHeader));
       uint32_t pdf[8];

@@ -4,8 +4,8 @@
   kernel argument, or a pointer carried across a loop edge) compiles to flat_load / flat_store; FLAT operations also
   tick the LDS counter, and with one of them pending the compiler turns every counted `s_waitcnt vmcnt(N)` of the rANS
   row loops into `vmcnt(0)` -- measured 183 -> 291 us on a decoder build that carried pointers through its pipeline
-  (DESIGN.md section 4.4).  `BatchView::ptr` and the kernels materialise global (address space 1) pointers instead.
-* No kernel spills to scratch (spill code waits for the loads it parks, which serialises prefetches: DESIGN.md s.3).
+  (docs/HISTORY.md section 4.4).  `BatchView::ptr` and the kernels materialise global (address space 1) pointers instead.
+* No kernel spills to scratch (spill code waits for the loads it parks, which serialises prefetches: docs/HISTORY.md section 3).
 """
 import os
 import re

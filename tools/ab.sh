@@ -2,7 +2,7 @@
 # A/B harness: tools/ab.sh <reps> <workload> <variant> ...
 #   variant = "base" | <lib relative to dietgpu_amd/lib/> , optionally followed by @ENV=VALUE[@ENV=VALUE...]
 #   (tools/build_variant.py makes dietgpu_amd/lib/v_<name>.so).  Variants are interleaved rep by rep -- the same build
-#   has placement-dependent modes between processes -- the last lines give the medians.
+#   has placement-dependent modes between processes (docs/HISTORY.md section 3) -- the last lines give the medians.
 #   Columns: cold = the headline loop (rotating buffer sets), warm = one buffer set; kernels in us (cold | warm).
 REPS=$1; WL=$2; shift 2
 rm -f /tmp/ab_*.txt
