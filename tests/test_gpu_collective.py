@@ -104,7 +104,9 @@ def test_pipelined_compressed_all_gather_single_rank_rccl():
         # launch of step k + 1 (different data per step: the two buffer sets must not be mixed up); the step with
         # incompressible rows falls back at ITS wait
         plan6 = D.CompressedAllGatherPlan(shard, chunks=2, depth=2)
-        inputs = [shard, mixed.clone(), shard.flip(0).contiguous(), shard]
+        noisy = shard.clone()
+        noisy[3], noisy[9] = noise[0], noise[1]
+        inputs = [shard, noisy, shard.flip(0).contiguous(), shard]
         handles = []
         for k, x in enumerate(inputs):
             handles.append(plan6.run_async(x))
