@@ -381,10 +381,12 @@ struct HistFuse {
 // conflicts: raw bytes 68 -> 58 us, exponents 50.5 -> 49 us).  The four
 // wavefronts of a workgroup share the same 32 KiB (ds_add is atomic; different
 // waves are different instructions and merely interleave).
-// Workgroups that see little data (many small elements) use 8 slots instead:
-// zeroing and folding 32 KiB of bins costs more than their few conflicts.
+// Workgroups that see little data (many small elements, <= 64 KiB per workgroup) use 16 slots instead: zeroing and
+// folding 32 KiB of bins costs more than the conflicts of 16 (measured on MI355X, k_float_histogram,
+// profiles/r05_ab_histogram_small_slots.txt: 16384 x 8 Ki bf16 62.4 us with 8 slots, 59.0 with 16, 84.5 with 32; sparse
+// fp16 at probBits 11 -- half the symbols are one value -- 72.0 / 58.7 / 87.2; 4 slots 75.5).
 constexpr uint32_t kHistSlotsLarge = 32;
-constexpr uint32_t kHistSlotsSmall = 8;
+constexpr uint32_t kHistSlotsSmall = 16;
 
 template <uint32_t S>
 __device__ __forceinline__ void histZero(uint32_t* bins, uint32_t tid) {
