@@ -947,7 +947,7 @@ bool histAccumulates(uint32_t B, uint32_t maxBytes, bool raw) {
 // ordered while calls on different streams may overlap.
 constexpr size_t kCounterWordsArrive = 65536;
 constexpr size_t kCounterWordsAcc = (size_t)kAccElements * kNumSymbols;
-constexpr size_t kCounterWordsSpill = 16384;  // flags of k_ans_encode_pair's spill-slot pool (kernels_encode.h: SpillPool)
+constexpr size_t kCounterWordsSpill = 16384;  // flags of the hardware-dispatched encoders' spill-slot pool (kernels_encode.h: SpillPool)
 int arrivalCounters(StreamLease& lease, uint32_t** out, uint32_t** acc, uint32_t** spillFlags = nullptr) {
   hipError_t e = hipSuccess;
   StreamState* s = lease.state(&e);
@@ -1025,10 +1025,11 @@ int encodeCommon(
   DGPU_ALLOC(tileDesc, uint64_t, arena, (size_t)B * std::max(maxTiles, 1u));
   DGPU_ALLOC(claims, uint32_t, arena, (size_t)B * std::max(maxTiles, 1u));
 
-  // The encoder's grid.  `resident` = the workgroups of the kernel that fit on the chip at once.  The tiled kernels run
-  // as `resident` persistent workgroups that walk the tickets with a static map, or -- raw bytes, when there are more
-  // tiles than that -- as one workgroup per tile, dispatched by the hardware in ticket order (encoderHardwareDispatch);
-  // k_ans_encode_pair is always persistent.  Spill slots (float inputs, persistent): [resident][slots per workgroup].
+  // The encoder's grid.  `resident` = the workgroups of the kernel that fit on the chip at once.  8-block float tiles
+  // run as `resident` persistent workgroups that walk the tickets with a static map; raw bytes and float tiles of 2 / 4
+  // blocks run one workgroup per tile when there are more tiles than that, dispatched by the hardware in ticket order
+  // (encoderHardwareDispatch); k_ans_encode_pair always runs one workgroup per pair.  Spill slots (float inputs):
+  // [resident][slots per workgroup] -- a persistent workgroup's own, or a pool handed out through spillFlags.
   const uint32_t numTickets = B * maxTiles;
   const uint32_t resident = maxTiles > 0 ? encodeGrid(P, floatType, tileBlocks, numTickets) : 0u;
   const bool hwDispatch = tileBlocks != kBlocksPerSingleTile && encoderHardwareDispatch(numTickets, resident, floatType, tileBlocks);

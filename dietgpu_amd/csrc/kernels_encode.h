@@ -111,10 +111,11 @@ struct EncodeArgs {
   uint64_t* tileDesc;        // [B][maxTiles], zeroed before launch (by the normalisation step)
   uint32_t* claims;          // [maxTiles][B] tile claim words, zeroed before launch
   uint32_t absentModulo;     // test hook: workgroups with index % absentModulo == 1 start ~0.5 ms late (0 = off)
-  uint16_t* spill;           // kSpill kernels only.  k_ans_encode (persistent grids): [gridDim.x][blocks per tile]
-                             // [encSpillSlotWords(P)], a workgroup's slots are its own.  k_ans_encode_pair (one workgroup
-                             // per pair, dispatched by the hardware): [spillPairs][2][encSpillSlotWords(P)], a POOL
-  uint32_t* spillFlags;      // k_ans_encode_pair: [spillPairs] 0 = free; library-owned, zero at rest (SpillPool)
+  uint16_t* spill;           // kSpill kernels only.  Persistent grids (k_ans_encode, 8-block float tiles): [gridDim.x][blocks
+                             // per tile][encSpillSlotWords(P)], a workgroup's slots are its own.  Hardware-dispatched grids
+                             // (k_ans_encode with 2- / 4-block float tiles, k_ans_encode_pair): [spillPairs][2]
+                             // [encSpillSlotWords(P)], a POOL
+  uint32_t* spillFlags;      // hardware-dispatched grids: [spillPairs] 0 = free; library-owned, zero at rest (SpillPool)
   uint32_t spillPairs;       // ... >= the wavefronts of the kernel that can be resident at once
   uint32_t* outSize;         // [B] nullable
   uint32_t outCapacity;      // bytes the caller has at out.ptr(b): block data beyond it is NOT stored (outSize still
@@ -351,8 +352,8 @@ __device__ __forceinline__ void stageWriteShiftUnder(uint64_t vote, uint32_t add
                : [s] "+v"(state), [sv] "=&s"(saved) : [a] "v"(addr), [v] "s"(vote) : "memory", "scc");
 }
 
-// Spill slots of a hardware-dispatched grid (k_ans_encode_pair: one workgroup per pair of elements, so blockIdx.x is no
-// bound on what is resident).  A wavefront that has to flush takes a PAIR of slots (one per half) out of a pool with
+// Spill slots of a hardware-dispatched grid (k_ans_encode_pair and the small float tiles of k_ans_encode: one workgroup
+// per pair of elements / per tile, so blockIdx.x is no bound on what is resident).  A wavefront that has to flush takes a PAIR of slots (one per half) out of a pool with
 // one flag word per pair and gives it back after its copy-out.  The pool has at least as many pairs as wavefronts of
 // the kernel can be resident and a wavefront holds at most one, so the probe terminates; the flags are zero at rest.
 // A slot changes hands between wavefronts on DIFFERENT XCDs, whose L2s are not coherent with each other: everything
@@ -362,7 +363,7 @@ struct SpillPool {
   uint16_t* base;
   uint32_t* flags;
   uint32_t pairs;
-  uint32_t pair;  // kNoSpillPair until this wavefront has taken one (for the current pair of elements)
+  uint32_t pair;  // kNoSpillPair until this wavefront has taken one (for the tile / pair of elements it is encoding)
 };
 constexpr uint32_t kNoSpillPair = 0xffffffffu;
 __device__ __forceinline__ uint32_t spillAcquire(const SpillPool& sp, uint32_t seed) {  // whole wavefront
