@@ -176,6 +176,16 @@ struct ChunkSource<0> {  // raw bytes: the symbols are the input
     return r;
   }
   __device__ __forceinline__ void consume(const Raw& r, uint32_t, uint32_t hl, uint8_t* ring) const { *(uint4*)(ring + hl * 16u) = r.v; }
+  // Tail forms (a block of n < 4096 symbols, 16-byte aligned input; see encodeRows, kTail): a 16-byte part of the
+  // lane's slice that begins at or beyond symbol n is not loaded; a part that straddles n is (it lies inside the
+  // 16-byte window that holds the element's last byte), its symbols beyond n are never coded.
+  __device__ __forceinline__ Raw loadTail(uint32_t c, uint32_t hl, uint32_t n) const {
+    Raw r;
+    r.v = make_uint4(0, 0, 0, 0);
+    if (c * 512u + hl * 16u < n) r.v = streamLoad<kNtEncLoads>(&((const uint4*)in)[c * 32u + hl]);
+    return r;
+  }
+  __device__ __forceinline__ void consumeTail(const Raw& r, uint32_t c, uint32_t hl, uint8_t* ring, uint32_t) const { consume(r, c, hl, ring); }
   // split without the ring write (fused kernel: the symbol bytes stay in registers for a while)
   static constexpr uint32_t kCompRegs = 4;
   __device__ __forceinline__ void splitStore(const Raw& r, uint32_t, uint32_t, uint32_t (&comp)[kCompRegs]) const {
@@ -216,7 +226,32 @@ struct ChunkSource16 {
   }
   // FloatTypeInfo<FT>::split (GpuFloatUtils.cuh:111-115, 141-147) on packed pairs: the non-compressed
   // bytes go to the archive, the compressed (exponent) bytes of the lane's 16 words are returned
-  __device__ __forceinline__ void splitStore(const Raw& r, uint32_t c, uint32_t hl, uint32_t (&comp)[kCompRegs]) const {
+  // Tail forms: see ChunkSource<0>.  Words at or beyond n inside a loaded part are set to zero, so that their
+  // non-compressed bytes -- which land in the plane's zero padding up to the next 16-byte boundary -- are zero; a lane
+  // whose slice lies wholly beyond n stores nothing.
+  __device__ __forceinline__ Raw loadTail(uint32_t c, uint32_t hl, uint32_t n) const {
+    const uint32_t first = c * 512u + hl * 16u;
+    const uint4* p = (const uint4*)(in + first);
+    Raw r;
+    r.a = r.b = make_uint4(0, 0, 0, 0);
+    if (first < n) r.a = streamLoad<kNtEncLoads>(&p[0]);
+    if (first + 8u < n) r.b = streamLoad<kNtEncLoads>(&p[1]);
+    return r;
+  }
+  __device__ __forceinline__ void consumeTail(const Raw& r, uint32_t c, uint32_t hl, uint8_t* ring, uint32_t n) const {
+    const uint32_t first = c * 512u + hl * 16u;
+    const uint32_t valid = n > first ? (n - first < 16u ? n - first : 16u) : 0u;  // words of the lane's slice that exist
+    auto keep = [&](uint32_t x, uint32_t j) -> uint32_t {  // dword j holds words 2 j, 2 j + 1 of the slice
+      return valid >= 2u * j + 2u ? x : (valid == 2u * j + 1u ? (x & 0xffffu) : 0u);
+    };
+    Raw m;
+    m.a = make_uint4(keep(r.a.x, 0), keep(r.a.y, 1), keep(r.a.z, 2), keep(r.a.w, 3));
+    m.b = make_uint4(keep(r.b.x, 4), keep(r.b.y, 5), keep(r.b.z, 6), keep(r.b.w, 7));
+    uint32_t comp[4];
+    splitStore(m, c, hl, comp, valid != 0u);
+    *(uint4*)(ring + hl * 16u) = make_uint4(comp[0], comp[1], comp[2], comp[3]);
+  }
+  __device__ __forceinline__ void splitStore(const Raw& r, uint32_t c, uint32_t hl, uint32_t (&comp)[kCompRegs], bool store = true) const {
     const uint32_t x[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w};
     uint32_t rest[4];
     if (FT == kFloat16) {
@@ -245,7 +280,7 @@ struct ChunkSource16 {
         rest[j] = packBytes02(q[2 * j + 1], q[2 * j]);
       }
     }
-    streamStore<kNtEncStores>(&((uint4*)(nc + c * 512u))[hl], make_uint4(rest[0], rest[1], rest[2], rest[3]));
+    if (store) streamStore<kNtEncStores>(&((uint4*)(nc + c * 512u))[hl], make_uint4(rest[0], rest[1], rest[2], rest[3]));
   }
   __device__ __forceinline__ uint32_t wordAt(uint32_t i) const { return in[i]; }
   __device__ __forceinline__ uint32_t splitAt(uint32_t i, uint32_t w, bool valid) const {
@@ -294,7 +329,28 @@ struct ChunkSource<kFloat32> {  // 4-byte words: comp byte + 24 non-comp bits (u
     *(uint2*)(ring + hl * 8u) = make_uint2(comp[0], comp[1]);
   }
   // FloatTypeInfo<kFloat32>::split (GpuFloatUtils.cuh:181-185): v = rotl(w, 1)
-  __device__ __forceinline__ void splitStore(const Raw& r, uint32_t c, uint32_t hl, uint32_t (&comp)[kCompRegs]) const {
+  // Tail forms: see ChunkSource16 (8 words per lane and chunk here, one per dword).
+  __device__ __forceinline__ Raw loadTail(uint32_t c, uint32_t hl, uint32_t n) const {
+    const uint32_t first = c * 256u + hl * 8u;
+    const uint4* p = (const uint4*)(in + first);
+    Raw r;
+    r.v[0] = r.v[1] = make_uint4(0, 0, 0, 0);
+    if (first < n) r.v[0] = streamLoad<kNtEncLoads>(&p[0]);
+    if (first + 4u < n) r.v[1] = streamLoad<kNtEncLoads>(&p[1]);
+    return r;
+  }
+  __device__ __forceinline__ void consumeTail(const Raw& r, uint32_t c, uint32_t hl, uint8_t* ring, uint32_t n) const {
+    const uint32_t first = c * 256u + hl * 8u;
+    const uint32_t valid = n > first ? (n - first < 8u ? n - first : 8u) : 0u;
+    auto keep = [&](uint32_t x, uint32_t j) -> uint32_t { return valid > j ? x : 0u; };
+    Raw m;
+    m.v[0] = make_uint4(keep(r.v[0].x, 0), keep(r.v[0].y, 1), keep(r.v[0].z, 2), keep(r.v[0].w, 3));
+    m.v[1] = make_uint4(keep(r.v[1].x, 4), keep(r.v[1].y, 5), keep(r.v[1].z, 6), keep(r.v[1].w, 7));
+    uint32_t comp[2];
+    splitStore(m, c, hl, comp, valid != 0u);
+    *(uint2*)(ring + hl * 8u) = make_uint2(comp[0], comp[1]);
+  }
+  __device__ __forceinline__ void splitStore(const Raw& r, uint32_t c, uint32_t hl, uint32_t (&comp)[kCompRegs], bool store = true) const {
     uint32_t v[8];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -314,8 +370,10 @@ struct ChunkSource<kFloat32> {  // 4-byte words: comp byte + 24 non-comp bits (u
       lo[2 * j + 0] = __builtin_amdgcn_perm(v[4 * j + 1], v[4 * j + 0], 0x05040100u);  // low 16 bits of two words
       lo[2 * j + 1] = __builtin_amdgcn_perm(v[4 * j + 3], v[4 * j + 2], 0x05040100u);
     }
-    streamStore<kNtEncStores>((uint4*)(nc2 + c * 256u + hl * 8u), make_uint4(lo[0], lo[1], lo[2], lo[3]));
-    *(uint2*)(nc1 + c * 256u + hl * 8u) = make_uint2(hi[0], hi[1]);
+    if (store) {
+      streamStore<kNtEncStores>((uint4*)(nc2 + c * 256u + hl * 8u), make_uint4(lo[0], lo[1], lo[2], lo[3]));
+      *(uint2*)(nc1 + c * 256u + hl * 8u) = make_uint2(hi[0], hi[1]);
+    }
   }
   __device__ __forceinline__ uint32_t wordAt(uint32_t i) const { return in[i]; }
   __device__ __forceinline__ uint32_t splitAt(uint32_t i, uint32_t w, bool valid) const {
@@ -413,7 +471,12 @@ static_assert(encGuardLimit(9, 120) + 256u <= encStageWords(9) + kEncGuardSlackW
               encGuardLimit(10, 120) + 256u <= encStageWords(10) + kEncGuardSlackWords &&
               encGuardLimit(11, 120) + 256u <= encStageWords(11) + kEncGuardSlackWords, "");
 // kPool (with kSpill): the slot comes from `pool` at the first flush instead of being `spill` (see SpillPool).
-template <int P, uint32_t FT, bool kFull, bool kSpill, bool kGuard = false, bool kPool = false>
+// kTail (with kFull): the chunked path for blocks that are NOT full -- the last block of an element, single-block
+// elements of any size -- on 16-byte aligned inputs: `n` symbols per half (0: idle half), `maxRows` rows, chunk loads
+// and non-compressed stores bounded by n (ChunkSource::loadTail / consumeTail), every row step predicated by
+// `symbol index < n`.  Three VALU more per row than the full-block step, against the scalar path's one memory round
+// trip per eight rows (256 x 530 000 bf16: encode 118 -> see profiles/r05_ab_partial_blocks.txt).
+template <int P, uint32_t FT, bool kFull, bool kSpill, bool kGuard = false, bool kPool = false, bool kTail = false>
 __device__ __forceinline__ uint32_t encodeRows(
     const ChunkSource<FT>& src,
     uint32_t n,                           // symbols in this half's block (0 = idle half)
@@ -429,6 +492,7 @@ __device__ __forceinline__ uint32_t encodeRows(
     bool& overrunOut,
     SpillPool* pool = nullptr) {
   static_assert(!kPool || kSpill, "");
+  static_assert(!kTail || kFull, "kTail is a mode of the chunked path");
   const uint32_t laneMaskLt = (1u << hl) - 1u;
   uint32_t state = kStartState;
   uint32_t outOff = 0;
@@ -456,7 +520,9 @@ __device__ __forceinline__ uint32_t encodeRows(
       spill = pool->base + ((size_t)pool->pair * 2u + (upper ? 1u : 0u)) * encSpillSlotWords(P);
     }
     uint4* dst = (uint4*)(spill + spilled);
-    for (uint32_t i = hl; i < nvec; i += 32u) {
+    uint32_t hlf = hl;  // (kPool: laundered, so that the 64-bit slot offsets of this rare path are computed here)
+    if constexpr (kPool) asm volatile("" : "+v"(hlf));
+    for (uint32_t i = hlf; i < nvec; i += 32u) {
       const u32x4e v = *(const LdsU4e*)(uintptr_t)(stageBase + 16u * i);
       if constexpr (kPool) coherentStore16(&dst[i], make_uint4(v.x, v.y, v.z, v.w));
       else dst[i] = make_uint4(v.x, v.y, v.z, v.w);
@@ -518,11 +584,13 @@ __device__ __forceinline__ uint32_t encodeRows(
     constexpr int kSymAhead = 4;
     constexpr uint32_t kChunkRows = ChunkSource<FT>::kRows;
     static_assert(kSymAhead > kAhead && kSymAhead <= (int)kChunkRows, "a symbol slot is reused only after its table load was issued");
-    typename ChunkSource<FT>::Raw cur = src.load(0, hl);
+    const uint32_t numChunks = kTail ? divUp(maxRows, kChunkRows) : kRowsPerBlock / kChunkRows;  // (uniform)
+    typename ChunkSource<FT>::Raw cur = kTail ? src.loadTail(0, hl, n) : src.load(0, hl);
 #pragma unroll 1
-    for (uint32_t c = 0; c < kRowsPerBlock / kChunkRows; ++c) {
-      src.consume(cur, c, hl, ring);
-      if (c + 1 < kRowsPerBlock / kChunkRows) cur = src.load(c + 1, hl);
+    for (uint32_t c = 0; c < numChunks; ++c) {
+      if (kTail) src.consumeTail(cur, c, hl, ring, n);
+      else src.consume(cur, c, hl, ring);
+      if (c + 1 < numChunks) cur = kTail ? src.loadTail(c + 1, hl, n) : src.load(c + 1, hl);
       auto symAt = [&](int r) -> uint32_t { return (uint32_t)ring[r * 32 + hl]; };
       auto fetchEntry = [&](uint32_t sym) -> uint4 { return ldsTableEntry(tableLds + (sym << 4)); };
       uint32_t sym[kSymAhead];
@@ -533,11 +601,14 @@ __device__ __forceinline__ uint32_t encodeRows(
       for (int r = 0; r < kAhead; ++r) e[r] = fetchEntry(sym[r]);
 #pragma unroll
       for (int r = 0; r < (int)kChunkRows; ++r) {
-        if (r % kFlushRows == 0) makeRoom(c * kChunkRows + (uint32_t)r);
+        const uint32_t row = c * kChunkRows + (uint32_t)r;
+        if (kTail && row >= maxRows) break;  // uniform (rows fetched ahead of the end read ring bytes nobody uses)
+        if (r % kFlushRows == 0) makeRoom(row);
         const uint4 cur_e = e[r % kAhead];
         if (r + kAhead < (int)kChunkRows) e[r % kAhead] = fetchEntry(sym[(r + kAhead) % kSymAhead]);
         if (r + kSymAhead < (int)kChunkRows) sym[r % kSymAhead] = symAt(r + kSymAhead);
-        stepFull(cur_e);
+        if (kTail) step(cur_e, row * 32u + hl < n);
+        else stepFull(cur_e);
       }
     }
   } else {
@@ -772,8 +843,13 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
           uint32_t beginA = firstBlockOfWave * kBlockSize;
           nA = size - beginA < kBlockSize ? size - beginA : kBlockSize;  // first half is never smaller than the second
         }
-        words = encodeRows<P, FT, false, kSpill, false, kPool>(src, n, divUp(nA, 32u), tableLds, stageLds, nullptr, hl, upper, spillSlot,
-                                                               spilled, state, overrun, &pool);
+        if (aligned) {  // uniform: the chunked path bounded by n (kTail); unaligned inputs take the scalar path
+          words = encodeRows<P, FT, true, kSpill, false, kPool, true>(src, n, divUp(nA, 32u), tableLds, stageLds, sRing + hw * 512u, hl,
+                                                                      upper, spillSlot, spilled, state, overrun, &pool);
+        } else {
+          words = encodeRows<P, FT, false, kSpill, false, kPool>(src, n, divUp(nA, 32u), tableLds, stageLds, nullptr, hl, upper, spillSlot,
+                                                                 spilled, state, overrun, &pool);
+        }
       }
 
       if (haveBlock) {
@@ -846,7 +922,9 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
           blockWords[blk] = make_uint2((bn << 16) | myWords, exclusive + (incl - myPadded));
         }
         if (tile == numTiles - 1 && (nb & 1u) && lane == kTB) {
-          blockWords[nb] = make_uint2(0u, 0u);  // alignment pad entry
+          uint32_t zero = 0;  // (made here: as a hoisted loop invariant this constant pair has been seen spilled to scratch)
+          asm volatile("" : "+v"(zero));
+          blockWords[nb] = make_uint2(zero, zero);  // alignment pad entry
         }
       }
       ldsBarrier();
@@ -863,7 +941,11 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
           const uint4* sp = (const uint4*)(kPool ? pool.base + ((size_t)pool.pair * 2u + (upper ? 1u : 0u)) * encSpillSlotWords(P) : spillSlot);
           uint32_t sv = spilled / kBlockAlignWords;
           const uint32_t svFit = sv < fit ? sv : fit;
-          for (uint32_t i = hl; i < svFit; i += 32u) streamStore<kNtEncStores>(&dst[i], kPool ? coherentLoad16(&sp[i]) : sp[i]);
+          // (the lane index is laundered: what this rare block derives from it -- 64-bit slot offsets -- is then computed
+          // here instead of being hoisted to the kernel's prologue, where it costs a register the row loops do not have)
+          uint32_t hls = hl;
+          asm volatile("" : "+v"(hls));
+          for (uint32_t i = hls; i < svFit; i += 32u) streamStore<kNtEncStores>(&dst[i], kPool ? coherentLoad16(&sp[i]) : sp[i]);
           dst += sv;
           fit -= svFit;
         }

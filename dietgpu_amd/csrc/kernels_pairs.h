@@ -248,8 +248,10 @@ __global__ __launch_bounds__(64) void k_ans_encode_pair(EncodeArgs a) {
     }
     pairLdsFence();  // tables in place
 
-    const bool fullMe = have && n == kBlockSize && (((uintptr_t)in & 15u) == 0);
+    const bool alignedMe = (((uintptr_t)in & 15u) == 0);
+    const bool fullMe = have && n == kBlockSize && alignedMe;
     const bool bothFull = __ballot(fullMe) == ~0ull;
+    const bool bothAligned = __ballot(have && !alignedMe) == 0ull;  // (a half without an element loads and stores nothing)
 
     ChunkSource<FT> src;
     src.init(in, archive, esize, 0u);
@@ -261,6 +263,11 @@ __global__ __launch_bounds__(64) void k_ans_encode_pair(EncodeArgs a) {
     if (bothFull) {
       words = encodeRows<P, FT, true, kSpill, !kSpill, kSpill>(src, n, kRowsPerBlock, tableLds, stageLds, ring, hl, upper, nullptr,
                                                         spilled, state, overrun, &pool);
+    } else if (bothAligned) {
+      // elements of any size below a block on aligned inputs: the chunked path bounded by n (encodeRows, kTail)
+      const uint32_t nMax = sLo > sHi ? sLo : sHi;
+      words = encodeRows<P, FT, true, kSpill, !kSpill, kSpill, true>(src, n, divUp(nMax, 32u), tableLds, stageLds, ring, hl, upper,
+                                                                     nullptr, spilled, state, overrun, &pool);
     } else {
       const uint32_t nMax = sLo > sHi ? sLo : sHi;
       words = encodeRows<P, FT, false, kSpill, !kSpill, kSpill>(src, n, divUp(nMax, 32u), tableLds, stageLds, nullptr, hl, upper,
