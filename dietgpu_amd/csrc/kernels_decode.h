@@ -28,6 +28,7 @@
 //         ONE load and stores 16 bytes (RowSink::flushGroup).  Otherwise the
 //         per-row sinks join and store one element per lane and row.
 #pragma once
+#include <type_traits>
 
 #include "format.h"
 #include "kernels_stats.h"
@@ -342,8 +343,14 @@ __device__ __forceinline__ void decodePrefetch(DecodePre& pre, const uint8_t* __
   }
 }
 
+// kTail (kFull): blocks that are NOT full -- the last block of an element, single-block elements of any size.  Only a
+// block's LAST row can have lanes without a symbol, so the rows split into `topRows` rows at the top (the partial row,
+// what is left of an incomplete 8-row group and -- two elements per wavefront -- the rows one half has and the other
+// has not), decoded in groups of eight by the predicated step with one-word stores, and `groups` whole groups below
+// them in which every lane of a half that has a block holds a symbol: those run the straight-line step with the wide
+// stores.  `n` = symbols of this half's block (0 with kIdleUpper: the upper half has none).
 template <int P, uint32_t FT, bool kFull, bool kWide = false, bool kIdleUpper = false, bool kCompact = false, bool kNoRing = false,
-          bool kPre = false>
+          bool kPre = false, bool kTail = false>
 __device__ __forceinline__ void decodeBlock(
     uint32_t xpose,                // kWide: LDS address of this half's transposition buffer
     uint32_t state,
@@ -356,8 +363,10 @@ __device__ __forceinline__ void decodeBlock(
     const RowSink<FT>& sink,
     uint32_t hl,
     bool upper,
-    const DecodePre* pre = nullptr) {  // kPre: the staging loads were issued by the caller (decodePrefetch)
+    const DecodePre* pre = nullptr,  // kPre: the staging loads were issued by the caller (decodePrefetch)
+    uint32_t topRows = 0) {          // kTail: rows above the `groups` whole groups (wave-uniform)
   static_assert(!kPre || (kNoRing && kFull), "");
+  static_assert(!kTail || (kFull && !kPre), "");
   constexpr uint32_t kMask = (1u << P) - 1u;
   const uint32_t laneMaskLt = (1u << hl) - 1u;
   // LUT entry of slot x as {pdf | sym << 24, x - cdf} (the compact form is unpacked here)
@@ -431,16 +440,8 @@ __device__ __forceinline__ void decodeBlock(
   // lanes that need to renormalise keep it.
   // wave-uniform positions (SGPRs): unread words of the lower / upper half's block; kNoRing: plus the LDS word
   // address of the block's staging area, so that (position + rank) << 1 IS the LDS address
-  constexpr bool kScalarPos = kFull;
+  typedef typename RowSink<FT>::Pre Pre;
   uint32_t sLo = 0, sHi = 0;
-  if (kScalarPos) {
-    sLo = __builtin_amdgcn_readlane(numWords, 0);
-    sHi = __builtin_amdgcn_readlane(numWords, 32);
-    if (kNoRing) {
-      sLo += __builtin_amdgcn_readlane(ringBase, 0) >> 1;
-      sHi += __builtin_amdgcn_readlane(ringBase, 32) >> 1;
-    }
-  }
   // an idle upper half follows the lower half's addresses (in bounds; its words are never used)
   int upperSel = (upper && !kIdleUpper) ? 1 : 0;
   asm volatile("" : "+v"(upperSel));  // a VGPR operand of the multiply-add, not a select to be folded into it
@@ -464,6 +465,9 @@ __device__ __forceinline__ void decodeBlock(
     return e.x;
   };
 
+  // Groups gHi .. gLo of the block, top down; F = every lane of a half that has a block holds a symbol in each of them
+  // (the straight-line step, wide stores where the sink has them), else the predicated step with one-word stores.
+  //
   // Non-compressed bytes are fetched ahead of their use: TWO groups on the wide path (a group takes ~1.5 us with three
   // workgroups per CU -- one group ahead did not cover the latency of HBM under load on cold buffers), one otherwise.
   //  * wide path: ONE 8-byte load per lane and group -- the 8 consecutive bytes that belong to the 8 consecutive
@@ -471,77 +475,97 @@ __device__ __forceinline__ void decodeBlock(
   //    costs no VALU for the join and no byte load;
   //  * otherwise one byte load per row, unconditional (row index clamped) so that the compiler can use counted
   //    vmcnt waits instead of draining the memory queue every group.
-  typedef typename RowSink<FT>::Pre Pre;
-  constexpr bool kJoinAtFlush = kFull && kWide;
-  Pre preCur[kGroupRows], preNext[kGroupRows];
-  const int lastGroup = (int)groups - 1;
-  uint2 ncCur = make_uint2(0, 0), ncNext = make_uint2(0, 0), ncNext2 = make_uint2(0, 0);
-  if (kJoinAtFlush) {
-    if (kPre) {
-      ncCur = pre->nc[0];
-      ncNext = pre->nc[1];
-    } else {
-      ncCur = sink.prefetchGroup((uint32_t)lastGroup, hl);
-      ncNext = sink.prefetchGroup(lastGroup > 0 ? (uint32_t)(lastGroup - 1) : 0u, hl);
+  auto runGroups = [&](auto fullTag, const int gHi, const int gLo) {
+    constexpr bool F = decltype(fullTag)::value;
+    constexpr bool kJoinAtFlush = F && kWide;
+    Pre preCur[kGroupRows], preNext[kGroupRows];
+    uint2 ncCur = make_uint2(0, 0), ncNext = make_uint2(0, 0), ncNext2 = make_uint2(0, 0);
+    if (kJoinAtFlush) {
+      if (kPre) {
+        ncCur = pre->nc[0];
+        ncNext = pre->nc[1];
+      } else {
+        ncCur = sink.prefetchGroup((uint32_t)gHi, hl);
+        ncNext = sink.prefetchGroup(gHi > gLo ? (uint32_t)(gHi - 1) : (uint32_t)gLo, hl);
+      }
     }
-  }
 #pragma unroll
-  for (int j = 0; j < (int)kGroupRows; ++j) {
-    const uint32_t row = (uint32_t)lastGroup * kGroupRows + j;
-    preCur[j] = kJoinAtFlush ? (Pre)0 : ((kFull || row * 32u + hl < n) ? sink.prefetch(row) : (Pre)0);
-  }
+    for (int j = 0; j < (int)kGroupRows; ++j) {
+      const uint32_t row = (uint32_t)gHi * kGroupRows + j;
+      preCur[j] = kJoinAtFlush ? (Pre)0 : ((F || row * 32u + hl < n) ? sink.prefetch(row) : (Pre)0);
+    }
 
 #pragma unroll 1
-  for (int g = lastGroup; g >= 0; --g) {
-    const uint32_t gNext = g > 0 ? (uint32_t)(g - 1) : 0u;
-    if (kJoinAtFlush) {
-      ncNext2 = sink.prefetchGroup(g > 1 ? (uint32_t)(g - 2) : 0u, hl);
-    } else {
-#pragma unroll
-      for (int j = 0; j < (int)kGroupRows; ++j) {
-        const uint32_t row = gNext * kGroupRows + j;
-        preNext[j] = (kFull || row * 32u + hl < n) ? sink.prefetch(row) : (Pre)0;
-      }
-    }
-    // ring maintenance
-    if (kScalarPos && !kNoRing) posw = upper ? sHi : sLo;
-    if (!kNoRing) {
-      if (pendingChunk >= 0) {
-        *(LdsU4*)(uintptr_t)(ringBase | (((uint32_t)pendingChunk & 3u) * 512u + hl * 16u)) = u32x4{pending.x, pending.y, pending.z, pending.w};
-        pendingChunk = -1;
-      }
-      if (lowChunk > 0 && (uint32_t)lowChunk * kRingChunkWords + 512u > posw) {
-        --lowChunk;
-        const uint32_t off = (uint32_t)lowChunk * 512u + hl * 16u;
-        pending = (off < paddedBytes) ? decLoad16(gwords + off) : make_uint4(0, 0, 0, 0);
-        pendingChunk = lowChunk;
-      }
-    }
-#pragma unroll
-    for (int j = (int)kGroupRows - 1; j >= 0; --j) {
-      const uint32_t row = (uint32_t)g * kGroupRows + j;
-      if (kFull) {
-        const uint32_t e0 = stepFull();
-        if (kWide) {
-          if (!kIdleUpper || !upper) sink.stageRow(xpose, (uint32_t)j, hl, e0);
-        } else if (!kIdleUpper || !upper) {
-          sink.store(row, e0, preCur[j]);
-        }
+    for (int g = gHi; g >= gLo; --g) {
+      const uint32_t gNext = g > gLo ? (uint32_t)(g - 1) : (uint32_t)gLo;
+      if (kJoinAtFlush) {
+        ncNext2 = sink.prefetchGroup(g > gLo + 1 ? (uint32_t)(g - 2) : (uint32_t)gLo, hl);
       } else {
-        const bool valid = row * 32u + hl < n;
-        const uint32_t e0 = step(valid);
-        if (valid) sink.store(row, e0, preCur[j]);
+#pragma unroll
+        for (int j = 0; j < (int)kGroupRows; ++j) {
+          const uint32_t row = gNext * kGroupRows + j;
+          preNext[j] = (F || row * 32u + hl < n) ? sink.prefetch(row) : (Pre)0;
+        }
+      }
+      // ring maintenance
+      if (F && !kNoRing) posw = upper ? sHi : sLo;
+      if (!kNoRing) {
+        if (pendingChunk >= 0) {
+          *(LdsU4*)(uintptr_t)(ringBase | (((uint32_t)pendingChunk & 3u) * 512u + hl * 16u)) = u32x4{pending.x, pending.y, pending.z, pending.w};
+          pendingChunk = -1;
+        }
+        if (lowChunk > 0 && (uint32_t)lowChunk * kRingChunkWords + 512u > posw) {
+          --lowChunk;
+          const uint32_t off = (uint32_t)lowChunk * 512u + hl * 16u;
+          pending = (off < paddedBytes) ? decLoad16(gwords + off) : make_uint4(0, 0, 0, 0);
+          pendingChunk = lowChunk;
+        }
+      }
+#pragma unroll
+      for (int j = (int)kGroupRows - 1; j >= 0; --j) {
+        const uint32_t row = (uint32_t)g * kGroupRows + j;
+        if (F) {
+          const uint32_t e0 = stepFull();
+          if (kWide) {
+            if (!kIdleUpper || !upper) sink.stageRow(xpose, (uint32_t)j, hl, e0);
+          } else if (!kIdleUpper || !upper) {
+            sink.store(row, e0, preCur[j]);
+          }
+        } else {
+          const bool valid = row * 32u + hl < n;
+          const uint32_t e0 = step(valid);
+          if (valid) sink.store(row, e0, preCur[j]);
+        }
+      }
+      if (kJoinAtFlush) {
+        if (!kIdleUpper || !upper) sink.flushGroup(xpose, (uint32_t)g, hl, ncCur);
+        ncCur = ncNext;
+        ncNext = ncNext2;
+      } else {
+#pragma unroll
+        for (int j = 0; j < (int)kGroupRows; ++j) preCur[j] = preNext[j];
       }
     }
-    if (kJoinAtFlush) {
-      if (!kIdleUpper || !upper) sink.flushGroup(xpose, (uint32_t)g, hl, ncCur);
-      ncCur = ncNext;
-      ncNext = ncNext2;
-    } else {
-#pragma unroll
-      for (int j = 0; j < (int)kGroupRows; ++j) preCur[j] = preNext[j];
+  };
+
+  if (kTail) {
+    // the groups above the whole ones, predicated (see the comment at the template); the ring, where there is one, is
+    // kept by the same per-group maintenance in both phases
+    if (topRows != 0u) runGroups(std::false_type{}, (int)(groups + divUp(topRows, kGroupRows)) - 1, (int)groups);
+    if (groups == 0u) return;  // uniform: the block had no whole group
+  }
+  if (kFull) {
+    // wave-uniform positions (SGPRs): unread words of the lower / upper half's block (numWords, less what the groups
+    // above consumed); kNoRing: plus the LDS word address of the block's staging area, so that (position + rank) << 1
+    // IS the LDS address
+    sLo = __builtin_amdgcn_readlane(posw, 0);
+    sHi = __builtin_amdgcn_readlane(posw, 32);
+    if (kNoRing) {
+      sLo += __builtin_amdgcn_readlane(ringBase, 0) >> 1;
+      sHi += __builtin_amdgcn_readlane(ringBase, 32) >> 1;
     }
   }
+  runGroups(std::integral_constant<bool, kFull>{}, (int)groups - 1, 0);
 }
 
 // grid = (maxTiles, B), 32 threads per block of the tile (512 or 128), LDS = word rings + 64-bit LUT.
@@ -846,8 +870,35 @@ __global__ __launch_bounds__(decThreads(kTileBlocks)) void k_ans_decode(DecodeAr
     }
 #undef DGPU_DECODE_FULL
   } else {
+    // A wavefront with a block that is not full -- the element's last: (full, partial) or (partial, none).  The whole
+    // 8-row groups in which every lane of a half that has a block holds a symbol run the straight-line step, the rows
+    // above them the predicated one (decodeBlock, kTail); in ring mode only if those rows fit the ring's initial fill.
     const uint32_t maxN = nFirst > nSecond ? nFirst : nSecond;
-    decodeBlock<P, FT, false, false, false, kCompact>(xpose, state, n, divUp(divUp(maxN, 32u), kGroupRows), gwords, numWords, ringLds, sLut, sink, hl, upper);
+    const uint32_t maxRows = divUp(maxN, 32u);
+    const uint32_t fullRows = (nSecond ? nSecond : nFirst) / 32u;  // (the last block of the wave is the partial one)
+    const uint32_t groups = fullRows / kGroupRows;
+    const uint32_t topRows = maxRows - groups * kGroupRows;
+    const bool tailPair = nFirst == kBlockSize && nSecond != 0u, tailSingle = nFirst != 0u && nSecond == 0u;
+    if ((tailPair || tailSingle) && groups != 0u) {
+#define DGPU_DECODE_TAIL(WIDE, IDLE, NORING) \
+  decodeBlock<P, FT, true, WIDE, IDLE, kCompact, NORING, false, true>(xpose, state, n, groups, gwords, numWords, ringLds, sLut, sink, hl, upper, nullptr, topRows)
+      if (tailPair) {
+        if (wide) {
+          if (noRing) DGPU_DECODE_TAIL(true, false, true); else DGPU_DECODE_TAIL(true, false, false);
+        } else {
+          if (noRing) DGPU_DECODE_TAIL(false, false, true); else DGPU_DECODE_TAIL(false, false, false);
+        }
+      } else {
+        if (wide) {
+          if (noRing) DGPU_DECODE_TAIL(true, true, true); else DGPU_DECODE_TAIL(true, true, false);
+        } else {
+          if (noRing) DGPU_DECODE_TAIL(false, true, true); else DGPU_DECODE_TAIL(false, true, false);
+        }
+      }
+#undef DGPU_DECODE_TAIL
+    } else {
+      decodeBlock<P, FT, false, false, false, kCompact>(xpose, state, n, divUp(maxRows, kGroupRows), gwords, numWords, ringLds, sLut, sink, hl, upper);
+    }
   }
 }
 

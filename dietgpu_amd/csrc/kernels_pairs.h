@@ -550,8 +550,24 @@ __global__ __launch_bounds__(64) void k_ans_decode_pair(DecodeArgs a) {
     }
 #undef DGPU_PAIR_DECODE_FULL
   } else {
-    const uint32_t maxN = nLo > nHi ? nLo : nHi;
-    decodeBlock<P, FT, false, false, false, true>(xpose, state, n, divUp(divUp(maxN, 32u), kGroupRows), gwords, numWords, ringBase, sLut, sink, hl, upper);
+    // Elements below a block: the whole 8-row groups BOTH halves fill run the straight-line step, the rows above them
+    // (each element's partial last row, the rows only the longer element has) the predicated one (decodeBlock, kTail)
+    const uint32_t maxN = nLo > nHi ? nLo : nHi, minN = nLo < nHi ? nLo : nHi;
+    const uint32_t maxRows = divUp(maxN, 32u);
+    const uint32_t groups = (minN / 32u) / kGroupRows;
+    const uint32_t topRows = maxRows - groups * kGroupRows;
+    if (groups != 0u) {  // (minN == 0: a half without an element -> the predicated path)
+#define DGPU_PAIR_DECODE_TAIL(WIDE, NORING) \
+  decodeBlock<P, FT, true, WIDE, false, true, NORING, false, true>(xpose, state, n, groups, gwords, numWords, ringBase, sLut, sink, hl, upper, nullptr, topRows)
+      if (wide) {
+        if (noRing) DGPU_PAIR_DECODE_TAIL(true, true); else DGPU_PAIR_DECODE_TAIL(true, false);
+      } else {
+        if (noRing) DGPU_PAIR_DECODE_TAIL(false, true); else DGPU_PAIR_DECODE_TAIL(false, false);
+      }
+#undef DGPU_PAIR_DECODE_TAIL
+    } else {
+      decodeBlock<P, FT, false, false, false, true>(xpose, state, n, divUp(maxRows, kGroupRows), gwords, numWords, ringBase, sLut, sink, hl, upper);
+    }
   }
 }
 

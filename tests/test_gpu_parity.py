@@ -1137,6 +1137,49 @@ def test_ragged_batches_of_small_elements(dg, prob_bits, blocks):
         assert all((tensor_to_words(ft, o) == w).all() for o, w in zip(outs, ws))
 
 
+@pytest.mark.parametrize("lead", [0, 1, 3, 8])
+def test_partial_last_blocks_at_every_row_count(dg, lead):
+    # elements of `lead` whole blocks + a last block of 1 .. 4095 symbols on both sides of every 8-row group boundary:
+    # both coders run the whole groups of such a block on the straight-line path and the rows above them predicated
+    # (encodeRows / decodeBlock, kTail) -- next to a whole block in the same wavefront, alone in it, or (lead 0) next
+    # to another element's block of a different length.  Compressible blocks are staged whole in LDS, incompressible
+    # ones go through the word ring (decoder) and the spill slots (float encoder).
+    rng = np.random.default_rng(9100 + lead)
+    lasts = [1, 31, 32, 33, 255, 256, 257, 288, 1023, 1024, 2049, 3585, 3840, 3841, 4064, 4065, 4095]
+    ns = [lead * 4096 + n for n in lasts] + [lead * 4096 + int(n) for n in rng.integers(1, 4096, 15)]
+    xs = []
+    for i, n in enumerate(ns):
+        x = rng.integers(0, 256, n, dtype=np.uint8) if i % 2 == 0 else refgen.generate_symbols(n, 20.0 + 30 * i)[:n]
+        xs.append(np.ascontiguousarray(x, np.uint8))
+    got = gpu_ans_encode(dg, xs, 10, True)
+    for x, g in zip(xs, got):
+        want = O.ans_encode(x, 10, use_checksum=True)
+        assert g.size == want.size and not (g != want).any(), ("raw", x.size)
+    outs, status, osz = gpu_ans_decode(dg, got, ns, 10, True)
+    assert status.all() and osz.tolist() == ns and all((o == x).all() for o, x in zip(outs, xs))
+    for ft in (O.BFLOAT16, O.FLOAT32):
+        dt = np.uint32 if ft == O.FLOAT32 else np.uint16
+        hi = 1 << (32 if ft == O.FLOAT32 else 16)
+        ws = []
+        for i, n in enumerate(ns):
+            w = rng.integers(0, hi, n, dtype=np.uint64).astype(dt) if i % 2 == 1 else refgen.generate_floats(ft, n)[:n]
+            ws.append(np.ascontiguousarray(w, dt))
+        ts = [words_to_tensor(ft, w) for w in ws]
+        comp, sizes, _ = dg.compress_data(True, ts, True, prob_bits=10)
+        hs, hc = sizes.cpu().numpy(), comp.cpu().numpy()
+        arch = []
+        for i, w in enumerate(ws):
+            want = O.float_compress(ft, w, 10, use_checksum=True)
+            assert hs[i] == want.size and not (hc[i, : hs[i]] != want).any(), (ft, w.size)
+            arch.append(comp[i, : hs[i]].clone())
+        outs = [torch.empty_like(t) for t in ts]
+        status = torch.zeros((len(ns),), dtype=torch.uint8, device=DEV)
+        osz = torch.zeros((len(ns),), dtype=torch.int32, device=DEV)
+        dg.decompress_data(True, arch, outs, True, None, status, osz, prob_bits=10)
+        assert status.cpu().numpy().all() and osz.cpu().tolist() == ns
+        assert all((tensor_to_words(ft, o) == w).all() for o, w in zip(outs, ws))
+
+
 def _single_block_count_vectors(rng, trials):
     """Byte rows of <= 4096 symbols whose histograms drive every branch of the normalisation: a few symbols, all 256,
     singletons next to one giant (the deficit branch: every count-1 symbol is lifted to probability 1), powers of two,
