@@ -475,7 +475,8 @@ static_assert(encGuardLimit(9, 120) + 256u <= encStageWords(9) + kEncGuardSlackW
 // elements of any size -- on 16-byte aligned inputs: `n` symbols per half (0: idle half), `maxRows` rows, chunk loads
 // and non-compressed stores bounded by n (ChunkSource::loadTail / consumeTail), every row step predicated by
 // `symbol index < n`.  Three VALU more per row than the full-block step, against the scalar path's one memory round
-// trip per eight rows (256 x 530 000 bf16: encode 118 -> see profiles/r05_ab_partial_blocks.txt).
+// trip per eight rows (bf16, 256 x 530 000: encode 120 -> 112 us, 32768 x 4000: 237 -> 138 us;
+// profiles/r05_ab_partial_blocks.txt).
 template <int P, uint32_t FT, bool kFull, bool kSpill, bool kGuard = false, bool kPool = false, bool kTail = false>
 __device__ __forceinline__ uint32_t encodeRows(
     const ChunkSource<FT>& src,
