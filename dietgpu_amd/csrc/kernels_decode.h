@@ -108,6 +108,7 @@ __device__ __forceinline__ uint2 decLoad8(const uint8_t* p) {
   }
   return *(const uint2*)p;
 }
+__host__ __device__ constexpr uint32_t decOutWordBytes(uint32_t ft) { return ft == 0u ? 1u : (ft == kFloat32 ? 4u : 2u); }
 __device__ __forceinline__ uint4 decLoad16(const uint8_t* p) { return streamLoad<kNtDecLoads>((const uint4*)p); }
 typedef __attribute__((address_space(3))) uint16_t LdsU16w;
 typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
@@ -713,7 +714,8 @@ __global__ __launch_bounds__(decThreads(kTileBlocks)) void k_ans_decode(DecodeAr
   const uint32_t wFirst = __shfl(numWords, 0, 64);
   const uint32_t wSecond = __shfl(numWords, 32, 64);
   const bool noRing = wFirst <= kRingBytes / 2u && wSecond <= kRingBytes / 2u;
-  const bool wide = decXposeBytes(P, FT, kTileBlocks) != 0 && (((uintptr_t)a.out.ptr(b)) & 15u) == 0;  // wide stores need a 16-byte aligned output element
+  // (the wide stores cover whole 8-row groups of words that exist; they take any word-aligned output element)
+  const bool wide = decXposeBytes(P, FT, kTileBlocks) != 0 && (((uintptr_t)a.out.ptr(b)) & (decOutWordBytes(FT) - 1u)) == 0;
   const bool fullPair = nFirst == kBlockSize && nSecond == kBlockSize;
   // one full block in the wave (odd block counts): fast path with an idle upper half
   const bool fullSingle = nFirst == kBlockSize && nSecond == 0u;

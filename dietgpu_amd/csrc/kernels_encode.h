@@ -162,6 +162,52 @@ __device__ __forceinline__ uint4 ldsTableEntry(uint32_t addr) {
 template <uint32_t FT>
 struct ChunkSource;
 
+// The lane's slice of kParts x 16 bytes at `base + begin` of a block that holds `nB` bytes, for the tail forms below
+// (encodeRows, kTail): a part wholly inside the block is loaded where it lies, whatever its alignment; a part at or
+// beyond nB is not loaded.  The one part that can STRADDLE nB is loaded where it lies when the parts are 16-byte aligned
+// windows (the window holds the block's last byte, so it cannot leave the page); otherwise the 16 bytes that END at the
+// block's last byte are loaded and shifted down -- no byte beyond the element is touched.  That load begins up to 15
+// bytes before the part: the caller sends elements below 16 bytes that are not 16-byte aligned to the scalar path
+// (encVectorLoadsOk).  Bytes at or beyond nB come back as zero or as whatever the aligned window held; the callers
+// mask them.
+template <uint32_t FT>
+__device__ __forceinline__ bool encVectorLoadsOk(const uint8_t* in, uint32_t size) {
+  constexpr uint32_t kWordBytes = FT == 0u ? 1u : (FT == kFloat32 ? 4u : 2u);
+  const uint32_t a = (uint32_t)(uintptr_t)in;
+  return (a & 15u) == 0 || ((a & (kWordBytes - 1u)) == 0 && (uint64_t)size * kWordBytes >= 16u);
+}
+template <uint32_t kParts>
+__device__ __forceinline__ void loadSliceBounded(const uint8_t* base, uint32_t begin, uint32_t nB, uint4 (&part)[kParts]) {
+  // (laundered: everything here that does not depend on the chunk would otherwise be kept in registers across the row
+  // loop, which has none to spare)
+  uint32_t lowBits = (uint32_t)(uintptr_t)base;
+  asm volatile("" : "+v"(lowBits));
+  const bool windows = (lowBits & 15u) == 0;  // (begin is a multiple of 16)
+  asm volatile("" : "+v"(nB), "+v"(begin));
+#pragma unroll
+  for (uint32_t k = 0; k < kParts; ++k) {
+    const uint32_t pb = begin + 16u * k;
+    uint32_t off = pb, sh = 0u;  // sh: bytes to drop at the bottom of what was loaded
+    bool ld = windows ? pb < nB : pb + 16u <= nB;
+    if (!windows && pb < nB && nB < pb + 16u) {
+      off = nB - 16u;
+      sh = pb + 16u - nB;  // 1 .. 15
+      ld = true;
+    }
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (ld) v = streamLoad<kNtEncLoads>((const uint4*)(base + (int32_t)off));
+    if (sh != 0u) {
+      if (sh & 8u) v = make_uint4(v.z, v.w, 0u, 0u);
+      if (sh & 4u) v = make_uint4(v.y, v.z, v.w, 0u);
+      v.x = __builtin_amdgcn_alignbyte(v.y, v.x, sh & 3u);
+      v.y = __builtin_amdgcn_alignbyte(v.z, v.y, sh & 3u);
+      v.z = __builtin_amdgcn_alignbyte(v.w, v.z, sh & 3u);
+      v.w = __builtin_amdgcn_alignbyte(0u, v.w, sh & 3u);
+    }
+    part[k] = v;
+  }
+}
+
 template <>
 struct ChunkSource<0> {  // raw bytes: the symbols are the input
   static constexpr uint32_t kRows = 16;  // rows per chunk
@@ -176,13 +222,14 @@ struct ChunkSource<0> {  // raw bytes: the symbols are the input
     return r;
   }
   __device__ __forceinline__ void consume(const Raw& r, uint32_t, uint32_t hl, uint8_t* ring) const { *(uint4*)(ring + hl * 16u) = r.v; }
-  // Tail forms (a block of n < 4096 symbols, 16-byte aligned input; see encodeRows, kTail): a 16-byte part of the
-  // lane's slice that begins at or beyond symbol n is not loaded; a part that straddles n is (it lies inside the
-  // 16-byte window that holds the element's last byte), its symbols beyond n are never coded.
+  // Tail forms (a block of n < 4096 symbols; see encodeRows, kTail, and loadSliceBounded): a 16-byte part of the
+  // lane's slice that begins at or beyond symbol n is not loaded; the symbols of a part that straddles n beyond n are
+  // never coded.
   __device__ __forceinline__ Raw loadTail(uint32_t c, uint32_t hl, uint32_t n) const {
+    uint4 part[1];
+    loadSliceBounded<1>(in, c * 512u + hl * 16u, n, part);
     Raw r;
-    r.v = make_uint4(0, 0, 0, 0);
-    if (c * 512u + hl * 16u < n) r.v = streamLoad<kNtEncLoads>(&((const uint4*)in)[c * 32u + hl]);
+    r.v = part[0];
     return r;
   }
   __device__ __forceinline__ void consumeTail(const Raw& r, uint32_t c, uint32_t hl, uint8_t* ring, uint32_t) const { consume(r, c, hl, ring); }
@@ -231,11 +278,11 @@ struct ChunkSource16 {
   // whose slice lies wholly beyond n stores nothing.
   __device__ __forceinline__ Raw loadTail(uint32_t c, uint32_t hl, uint32_t n) const {
     const uint32_t first = c * 512u + hl * 16u;
-    const uint4* p = (const uint4*)(in + first);
+    uint4 part[2];
+    loadSliceBounded<2>((const uint8_t*)in, first * 2u, n * 2u, part);
     Raw r;
-    r.a = r.b = make_uint4(0, 0, 0, 0);
-    if (first < n) r.a = streamLoad<kNtEncLoads>(&p[0]);
-    if (first + 8u < n) r.b = streamLoad<kNtEncLoads>(&p[1]);
+    r.a = part[0];
+    r.b = part[1];
     return r;
   }
   __device__ __forceinline__ void consumeTail(const Raw& r, uint32_t c, uint32_t hl, uint8_t* ring, uint32_t n) const {
@@ -332,11 +379,8 @@ struct ChunkSource<kFloat32> {  // 4-byte words: comp byte + 24 non-comp bits (u
   // Tail forms: see ChunkSource16 (8 words per lane and chunk here, one per dword).
   __device__ __forceinline__ Raw loadTail(uint32_t c, uint32_t hl, uint32_t n) const {
     const uint32_t first = c * 256u + hl * 8u;
-    const uint4* p = (const uint4*)(in + first);
     Raw r;
-    r.v[0] = r.v[1] = make_uint4(0, 0, 0, 0);
-    if (first < n) r.v[0] = streamLoad<kNtEncLoads>(&p[0]);
-    if (first + 4u < n) r.v[1] = streamLoad<kNtEncLoads>(&p[1]);
+    loadSliceBounded<2>((const uint8_t*)in, first * 4u, n * 4u, r.v);
     return r;
   }
   __device__ __forceinline__ void consumeTail(const Raw& r, uint32_t c, uint32_t hl, uint8_t* ring, uint32_t n) const {
@@ -472,7 +516,7 @@ static_assert(encGuardLimit(9, 120) + 256u <= encStageWords(9) + kEncGuardSlackW
               encGuardLimit(11, 120) + 256u <= encStageWords(11) + kEncGuardSlackWords, "");
 // kPool (with kSpill): the slot comes from `pool` at the first flush instead of being `spill` (see SpillPool).
 // kTail (with kFull): the chunked path for blocks that are NOT full -- the last block of an element, single-block
-// elements of any size -- on 16-byte aligned inputs: `n` symbols per half (0: idle half), `maxRows` rows, chunk loads
+// elements of any size -- on word-aligned inputs (encVectorLoadsOk): `n` symbols per half (0: idle half), `maxRows` rows, chunk loads
 // and non-compressed stores bounded by n (ChunkSource::loadTail / consumeTail), every row step predicated by
 // `symbol index < n`.  Three VALU more per row than the full-block step, against the scalar path's one memory round
 // trip per eight rows (bf16, 256 x 530 000: encode 120 -> 112 us, 32768 x 4000: 237 -> 138 us;
@@ -818,7 +862,9 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
       }
       // wave-uniform: are both halves full blocks (and the input vector-aligned)?
       const uint32_t firstBlockOfWave = tile * kTB + wave * 2u;
-      const bool aligned = (((uintptr_t)in & 15u) == 0);
+      // (vector loads take any word-aligned address -- elements of a split tensor, rows of a matrix; an element below 16
+      // bytes must be a 16-byte aligned window for the tail form's last load, see loadSliceBounded)
+      const bool aligned = encVectorLoadsOk<FT>(in, size);
       const bool waveFull = (uint64_t)(firstBlockOfWave + 2u) * kBlockSize <= (uint64_t)size && aligned;
       // ONE full block in the wave and no second one (odd block counts): the
       // lower half keeps the straight-line path; the upper half shadows it -- same block, same table, the same
@@ -844,7 +890,7 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
           uint32_t beginA = firstBlockOfWave * kBlockSize;
           nA = size - beginA < kBlockSize ? size - beginA : kBlockSize;  // first half is never smaller than the second
         }
-        if (aligned) {  // uniform: the chunked path bounded by n (kTail); unaligned inputs take the scalar path
+        if (aligned) {  // uniform: the chunked path bounded by n (kTail); else the scalar path
           words = encodeRows<P, FT, true, kSpill, false, kPool, true>(src, n, divUp(nA, 32u), tableLds, stageLds, sRing + hw * 512u, hl,
                                                                       upper, spillSlot, spilled, state, overrun, &pool);
         } else {
@@ -976,12 +1022,16 @@ __global__ __launch_bounds__(256) void k_float_histogram(BatchView in, uint32_t*
 
   const uint32_t n = in.size(b);
   const uint8_t* inBytes = in.ptr(b);
-  const bool aligned = (((uintptr_t)inBytes) & 15u) == 0;
-
-  constexpr uint32_t kWordsPerVec = FT == kFloat32 ? 4u : 8u;
-  const uint32_t numVec = aligned ? n / kWordsPerVec : 0u;
+  // words before the first 16-byte boundary (elements of a split tensor and rows of a matrix start anywhere; a count
+  // does not care about order, so the vectors simply start at the boundary)
+  constexpr uint32_t kWordBytes = FT == kFloat32 ? 4u : 2u;
+  constexpr uint32_t kWordsPerVec = 16u / kWordBytes;
+  const bool wordAligned = (((uintptr_t)inBytes) & (kWordBytes - 1u)) == 0;
+  uint32_t head = wordAligned ? (uint32_t)((16u - ((uintptr_t)inBytes & 15u)) & 15u) / kWordBytes : n;
+  head = head < n ? head : n;
+  const uint32_t numVec = (n - head) / kWordsPerVec;
   const uint32_t stride = gridDim.x * 256u;
-  const uint4* pv = (const uint4*)inBytes;
+  const uint4* pv = (const uint4*)(inBytes + (size_t)head * kWordBytes);
 
   auto addVec = [&](const uint4& x) {
     if (FT == kFloat32) {
@@ -1017,8 +1067,10 @@ __global__ __launch_bounds__(256) void k_float_histogram(BatchView in, uint32_t*
   }
   for (; v < vEnd; v += 256u) addVec(streamLoad<kNt>(&pv[v]));
 
-  // tail (and the whole element when the input is not 16-byte aligned)
-  for (uint32_t i = numVec * kWordsPerVec + blockIdx.x * 256u + tid; i < n; i += stride) {
+  // head and tail, word by word (the whole element when the input is not even word-aligned)
+  const uint32_t loose = n - numVec * kWordsPerVec;
+  for (uint32_t j = blockIdx.x * 256u + tid; j < loose; j += stride) {
+    const uint32_t i = j < head ? j : numVec * kWordsPerVec + j;
     uint32_t c;
     if (FT == kFloat32) c = (((const uint32_t*)inBytes)[i] >> 23) & 0xffu;
     else c = ((uint32_t)((const uint16_t*)inBytes)[i] >> (FT == kFloat16 ? 8u : 7u)) & 0xffu;

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64) void k_ans_encode_pair(EncodeArgs a) {
     }
     pairLdsFence();  // tables in place
 
-    const bool alignedMe = (((uintptr_t)in & 15u) == 0);
+    const bool alignedMe = encVectorLoadsOk<FT>(in, n);  // (vector loads take any word-aligned address)
     const bool fullMe = have && n == kBlockSize && alignedMe;
     const bool bothFull = __ballot(fullMe) == ~0ull;
     const bool bothAligned = __ballot(have && !alignedMe) == 0ull;  // (a half without an element loads and stores nothing)
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64) void k_ans_encode_pair(EncodeArgs a) {
       words = encodeRows<P, FT, true, kSpill, !kSpill, kSpill>(src, n, kRowsPerBlock, tableLds, stageLds, ring, hl, upper, nullptr,
                                                         spilled, state, overrun, &pool);
     } else if (bothAligned) {
-      // elements of any size below a block on aligned inputs: the chunked path bounded by n (encodeRows, kTail)
+      // elements of any size below a block on word-aligned inputs: the chunked path bounded by n (encodeRows, kTail)
       const uint32_t nMax = sLo > sHi ? sLo : sHi;
       words = encodeRows<P, FT, true, kSpill, !kSpill, kSpill, true>(src, n, divUp(nMax, 32u), tableLds, stageLds, ring, hl, upper,
                                                                      nullptr, spilled, state, overrun, &pool);
@@ -472,8 +472,8 @@ __global__ __launch_bounds__(64) void k_ans_decode_pair(DecodeArgs a) {
   const uint32_t nHi = __shfl(n, 32, 64);
   const uint32_t wLo = __shfl(numWords, 0, 64);
   const uint32_t wHi = __shfl(numWords, 32, 64);
-  // wide stores need 16-byte aligned output elements
-  const bool wide = kXpose != 0 && __ballot((((uintptr_t)outPtr) & 15u) != 0) == 0ull;
+  // (the wide stores cover whole 8-row groups of words that exist; they take any word-aligned output element)
+  const bool wide = kXpose != 0 && __ballot((((uintptr_t)outPtr) & (decOutWordBytes(FT) - 1u)) != 0) == 0ull;
   const bool fullBoth = nLo == kBlockSize && nHi == kBlockSize;
   // both blocks small enough to be staged whole (every exponent block of N(0,1) bf16 has ~650 words): the cheaper
   // row loop of decodeBlock (kNoRing), fed by the prefetch

@@ -98,6 +98,10 @@ def tensor_to_words(ft, t):
     return v.view(np.uint32 if ft == O.FLOAT32 else np.uint16)
 
 
+def roundup(n, m):
+    return (n + m - 1) // m * m
+
+
 def gpu_ans_encode(dg, xs, prob_bits=10, checksum=False, temp=None):
     ts = [to_dev_bytes(x) for x in xs]
     comp, sizes, _ = dg.compress_data(False, ts, checksum, temp, prob_bits=prob_bits)
@@ -719,7 +723,7 @@ def test_encoder_with_absent_workgroups(dg, modulo):
 
 @pytest.mark.parametrize("ft", [O.FLOAT16, O.BFLOAT16, O.FLOAT32])
 def test_float_unaligned_io(dg, ft):
-    # inputs / outputs that are only float-word aligned (scalar paths)
+    # inputs / outputs that are only float-word aligned
     n = 20000
     w = refgen.generate_floats(ft, n + 3)
     base = words_to_tensor(ft, w)
@@ -732,6 +736,63 @@ def test_float_unaligned_io(dg, ft):
     out = outbuf[1 : 1 + n]
     dg.decompress_data(True, [comp[0, : want.size].clone()], [out])
     assert (tensor_to_words(ft, out) == w[3:]).all()
+
+
+@pytest.mark.parametrize("small", [True, False])
+@pytest.mark.parametrize("ft", [0, O.FLOAT16, O.BFLOAT16, O.FLOAT32])
+def test_elements_at_every_word_alignment(dg, ft, small):
+    # elements of a split tensor / rows of a matrix start anywhere: the vector paths of histogram, encoder and decoder
+    # take every word-aligned address (raw bytes: every 4-byte aligned one, the C ABI's requirement).  Element i starts
+    # i words (raw: 4 i bytes) past a 16-byte boundary, its output (i + 3) words past one; sizes put the element's end on
+    # both sides of every 16-byte part of a lane's slice (the encoder loads the part that straddles the end as the 16
+    # bytes that END there), below 16 bytes (scalar path), on whole blocks and tiles; `small`: every element fits one
+    # block (the kernels that take a pair of elements per wavefront).
+    rng = np.random.default_rng(515 + 7 * ft + int(small))
+    wb = 1 if ft == 0 else (4 if ft == O.FLOAT32 else 2)
+    dt = {1: np.uint8, 2: np.uint16, 4: np.uint32}[wb]
+    step = 4 if ft == 0 else 1  # words between successive misalignments
+    per16 = 16 // wb
+    ns = [1, 2, 3, 5, 7, 8, 9, 15, 16, 17, 23, 24, 25, 31, 32, 33, 100, 511, 513, 2047, 4000, 4001, 4002, 4003, 4005, 4009, 4095, 4096]
+    ns += [int(n) for n in rng.integers(1, 4097, 12)]
+    if not small:
+        ns += [4097, 8191, 8192, 8193, 4096 * 3 + 5, 4096 * 8, 4096 * 8 + 123, 4096 * 17 + 1, 4096 * 40 - 3]
+    ws = []
+    for i, n in enumerate(ns):
+        if ft == 0:
+            w = rng.integers(0, 256, n, dtype=np.uint8) if i % 3 == 0 else refgen.generate_symbols(n, 20.0 + 30 * i)[:n]
+        else:
+            w = rng.integers(0, 1 << (8 * wb), n, dtype=np.uint64).astype(dt) if i % 3 == 0 else refgen.generate_floats(ft, n)[:n]
+        ws.append(np.ascontiguousarray(w, dt))
+    room = sum(roundup(n, per16) + 2 * per16 for n in ns) + 64
+    host_in = np.zeros(room, dt)
+    offs_in, offs_out, pos = [], [], 0
+    for i, n in enumerate(ns):
+        mis = (i * step) % per16
+        offs_in.append(pos + mis)
+        offs_out.append(pos + (mis + 3 * step) % per16)
+        host_in[pos + mis : pos + mis + n] = ws[i]
+        pos += roundup(n, per16) + 2 * per16
+    dev_in = torch.from_numpy(host_in).to(DEV) if ft == 0 else words_to_tensor(ft, host_in)
+    dev_out = torch.zeros_like(dev_in)
+    assert dev_in.data_ptr() % 16 == 0 and dev_out.data_ptr() % 16 == 0
+    ins = [dev_in[o : o + n] for o, n in zip(offs_in, ns)]
+    outs = [dev_out[o : o + n] for o, n in zip(offs_out, ns)]
+    comp, sizes, _ = dg.compress_data(ft != 0, ins, True)
+    hs, hc = sizes.cpu().numpy(), comp.cpu().numpy()
+    arch = []
+    for i, w in enumerate(ws):
+        want = O.float_compress(ft, w, 10, use_checksum=True) if ft else O.ans_encode(w, 10, use_checksum=True)
+        assert hs[i] == want.size and not (hc[i, : hs[i]] != want).any(), (ft, w.size, offs_in[i] % per16)
+        arch.append(comp[i, : hs[i]].clone())
+    status = torch.zeros((len(ns),), dtype=torch.uint8, device=DEV)
+    osz = torch.zeros((len(ns),), dtype=torch.int32, device=DEV)
+    dg.decompress_data(ft != 0, arch, outs, True, None, status, osz)
+    assert status.cpu().numpy().all() and osz.cpu().tolist() == ns
+    got = dev_out.cpu().numpy() if ft == 0 else tensor_to_words(ft, dev_out)
+    want_out = np.zeros(room, dt)
+    for o, w in zip(offs_out, ws):
+        want_out[o : o + w.size] = w
+    assert (got == want_out).all()  # every element restored, and not a word outside the elements written
 
 
 def test_float_simple_and_empty(dg):
