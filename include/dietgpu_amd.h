@@ -15,7 +15,9 @@
  *   - everything is enqueued on `stream` (a hipStream_t passed as void*); no
  *     host synchronisation happens unless a checksum has to be verified.
  *   - ANS inputs must be 4-byte aligned (kANSRequiredAlignment); float inputs
- *     float-word aligned; compressed buffers 16-byte aligned.
+ *     float-word aligned; compressed buffers 16-byte aligned.  Nothing more is
+ *     needed for speed: uncompressed elements at any such address (elements of
+ *     a split tensor, rows of a matrix) take the vector paths of every kernel.
  *   - probBits must be 9, 10 or 11.
  *
  * Temporary memory: the reference threads a `StackDeviceMemory&` through every
