@@ -711,6 +711,7 @@ struct HostParams {
   std::vector<uint64_t> inPtrs, outPtrs;
   std::vector<uint32_t> sizes;
   std::vector<uint32_t> inBytes;  // decode, *_bounded entry points: bytes available per compressed input
+  std::vector<uint32_t> work;     // work lists of a batch whose elements differ widely in size (RaggedPlan)
 };
 
 bool streamIsCapturing(hipStream_t stream) {
@@ -725,9 +726,11 @@ bool streamIsCapturing(hipStream_t stream) {
 int uploadParams(
     ParamLease& lease, hipStream_t stream, const HostParams& hp,
     const uint64_t** inPtrs_dev, const uint64_t** outPtrs_dev, const uint32_t** sizes_dev,
-    const uint32_t** inBytes_dev = nullptr) {
+    const uint32_t** inBytes_dev = nullptr, const uint32_t** work_dev = nullptr) {
   const size_t nIn = hp.inPtrs.size(), nOut = hp.outPtrs.size(), nSz = hp.sizes.size(), nIb = hp.inBytes.size();
-  const size_t bytes = (nIn + nOut) * 8 + alignUp(nSz * 4, 8) + alignUp(nIb * 4, 8);
+  const size_t nWk = work_dev ? hp.work.size() : 0;
+  const size_t workAt = (nIn + nOut) * 8 + alignUp(nSz * 4, 8) + alignUp(nIb * 4, 8);
+  const size_t bytes = workAt + alignUp(nWk * 4, 8);
   if (bytes == 0) return DGPU_OK;
   static thread_local std::vector<uint8_t> block;
   block.assign(bytes, 0);
@@ -736,6 +739,7 @@ int uploadParams(
   if (nOut) memcpy(h + nIn * 8, hp.outPtrs.data(), nOut * 8);
   if (nSz) memcpy(h + (nIn + nOut) * 8, hp.sizes.data(), nSz * 4);
   if (nIb) memcpy(h + (nIn + nOut) * 8 + alignUp(nSz * 4, 8), hp.inBytes.data(), nIb * 4);
+  if (nWk) memcpy(h + workAt, hp.work.data(), nWk * 4);
   ParamCache::Entry* entry = nullptr;
   bool miss = false;
   {
@@ -750,6 +754,7 @@ int uploadParams(
   *outPtrs_dev = nOut ? (const uint64_t*)(dev + nIn * 8) : nullptr;
   *sizes_dev = nSz ? (const uint32_t*)(dev + (nIn + nOut) * 8) : nullptr;
   if (inBytes_dev) *inBytes_dev = nIb ? (const uint32_t*)(dev + (nIn + nOut) * 8 + alignUp(nSz * 4, 8)) : nullptr;
+  if (work_dev) *work_dev = nWk ? (const uint32_t*)(dev + workAt) : nullptr;
   return DGPU_OK;
 }
 
@@ -937,6 +942,80 @@ bool encoderHardwareDispatch(uint32_t numTickets, uint32_t resident, uint32_t fl
   return numTickets > resident;  // more tiles than slots: let the hardware balance them
 }
 
+// Batches whose elements differ widely in size -- the tensors of a model in one call: a few matrices, many vectors.
+// The grids of the histogram, the encoder and the decoder are rectangles laid out for the LARGEST element (as
+// upstream's are); with one 32 Mi-word tensor next to 255 small ones that is 262 144 encoder tickets of which 1 279
+// exist, spread over the persistent workgroups by a static map that hands the large tensor's tiles to three of them,
+// and two histogram workgroups for its 64 MiB (tools/ragged_probe.py: 5.7 ms per compress call against 56 us + 37 us
+// for the two size classes on their own).  The host knows the sizes (they arrive as host arrays), so for such a batch
+// it lists the work that exists -- HostParams::work, uploaded with the pointers -- and the kernels take their
+// (element, tile / part) from the list instead of from the rectangle:
+//   * tiles (encoder, decoder): tile-major, as the rectangle's ticket order -- a tile's predecessor has a smaller
+//     ticket -- with the elements of a round in descending size;
+//   * histogram parts: every element cut into parts of histPartBytes (chosen for the usual number of workgroups over
+//     the WHOLE batch), element-major, so that an element's partial histograms are consecutive.
+// Used when at least half of the rectangle's tiles do not exist; dgpu_debug_set_work_lists forces it on (1: whenever
+// the batch has a size array) or off (0) for tests.
+inline uint64_t divUp64(uint64_t a, uint64_t b) { return (a + b - 1u) / b; }
+inline uint64_t roundUp64(uint64_t a, uint64_t b) { return divUp64(a, b) * b; }
+struct RaggedPlan {
+  bool use = false;
+  uint32_t numTiles = 0;      // entries of the tile list, first in HostParams::work
+  uint32_t numHistParts = 0;  // entries of the histogram list behind it (encode only)
+  uint32_t histPartBytes = 0;
+};
+std::atomic<int> g_workLists{[] {
+  const char* e = getenv("DGPU_WORK_LISTS");
+  return e && *e ? atoi(e) : -1;
+}()};
+// tiles of `tileSymbols` symbols; minTiles: 1 where an element without symbols still needs its first tile (decode)
+bool planTileList(const std::vector<uint32_t>& sizes, uint32_t tileSymbols, uint32_t maxTiles, uint32_t minTiles, std::vector<uint32_t>* work) {
+  const int mode = g_workLists.load();
+  const size_t B = sizes.size();
+  if (mode == 0 || B == 0 || B > 65535u || maxTiles > 65536u || tileSymbols == 0) return false;
+  std::vector<uint32_t> tiles(B);
+  uint64_t total = 0;
+  for (size_t b = 0; b < B; ++b) {
+    tiles[b] = std::max(divUp(sizes[b], tileSymbols), minTiles);
+    total += tiles[b];
+  }
+  if (mode != 1 && (B < 2 || maxTiles < 2 || total * 2u > (uint64_t)B * maxTiles)) return false;
+  if (total > 0x7fffffffull) return false;
+  std::vector<uint32_t> order(B);
+  for (size_t b = 0; b < B; ++b) order[b] = (uint32_t)b;
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return tiles[x] > tiles[y]; });
+  work->reserve(work->size() + (size_t)total);
+  for (uint32_t r = 0; r < maxTiles; ++r) {
+    for (size_t i = 0; i < B && tiles[order[i]] > r; ++i) work->push_back((order[i] << 16) | r);
+  }
+  return true;
+}
+constexpr uint32_t kHistTargetWgsForLists = 512, kHistTargetWgsForListsRaw = 768;
+void planHistList(const std::vector<uint32_t>& sizes, uint32_t wordBytes, bool raw, RaggedPlan* plan, std::vector<uint32_t>* work) {
+  uint64_t totalBytes = 0;
+  for (uint32_t sz : sizes) totalBytes += (uint64_t)sz * wordBytes;
+  const uint64_t target = raw ? kHistTargetWgsForListsRaw : kHistTargetWgsForLists;
+  const uint64_t partBytes = std::max<uint64_t>(32u * 1024u, roundUp64(divUp64(totalBytes, target), 16u * 1024u));
+  plan->histPartBytes = (uint32_t)std::min<uint64_t>(partBytes, 0x40000000ull);
+  const size_t before = work->size();
+  for (size_t b = 0; b < sizes.size(); ++b) {
+    const uint64_t bytes = (uint64_t)sizes[b] * wordBytes;
+    const uint32_t parts = (uint32_t)std::max<uint64_t>(1u, divUp64(bytes, plan->histPartBytes));
+    for (uint32_t p = 0; p < parts; ++p) work->push_back(((uint32_t)b << 16) | p);
+  }
+  plan->numHistParts = (uint32_t)(work->size() - before);
+}
+// Work lists of an encode call: false = the rectangles.
+bool planEncode(const std::vector<uint32_t>& sizes, uint32_t floatType, uint32_t maxSize, bool needHist, RaggedPlan* plan, std::vector<uint32_t>* work) {
+  const uint32_t tileBlocks = encTileBlocksFor(maxSize);
+  if (tileBlocks == kBlocksPerSingleTile) return false;  // single-block batches: one wavefront per element, nothing to list
+  if (!planTileList(sizes, tileBlocks * kBlockSize, tilesFor(maxSize), 0u, work)) return false;
+  plan->use = true;
+  plan->numTiles = (uint32_t)work->size();
+  if (needHist) planHistList(sizes, floatType ? floatWordBytes(floatType) : 1u, floatType == 0, plan, work);
+  return true;
+}
+
 bool histAccumulates(uint32_t B, uint32_t maxBytes, bool raw) {
   return B <= kHistAccMaxBatch && histPartsAccFor(B, maxBytes) > histPartsFor(B, maxBytes, raw);
 }
@@ -996,7 +1075,8 @@ int encodeCommon(
     TempArena& arena, StreamLease& lease, hipStream_t stream, int P, bool useChecksum, uint32_t B,
     const BatchView& in, const BatchView& archives, uint32_t floatType, uint32_t maxSize,
     const uint32_t* hist_dev /*may be null*/, uint32_t* outSize_dev,
-    uint32_t outCapacity = 0xffffffffu /* bytes at every archive pointer; block data beyond it is dropped */) {
+    uint32_t outCapacity = 0xffffffffu /* bytes at every archive pointer; block data beyond it is dropped */,
+    const RaggedPlan* plan = nullptr, const uint32_t* work_dev = nullptr /* the plan's lists on the device */) {
   const uint32_t wordBytes = floatType ? floatWordBytes(floatType) : 1u;
   const uint32_t maxTiles = tilesFor(maxSize);
 
@@ -1030,7 +1110,8 @@ int encodeCommon(
   // blocks run one workgroup per tile when there are more tiles than that, dispatched by the hardware in ticket order
   // (encoderHardwareDispatch); k_ans_encode_pair always runs one workgroup per pair.  Spill slots (float inputs):
   // [resident][slots per workgroup] -- a persistent workgroup's own, or a pool handed out through spillFlags.
-  const uint32_t numTickets = B * maxTiles;
+  const bool lists = plan && plan->use && work_dev;
+  const uint32_t numTickets = lists ? plan->numTiles : B * maxTiles;
   const uint32_t resident = maxTiles > 0 ? encodeGrid(P, floatType, tileBlocks, numTickets) : 0u;
   const bool hwDispatch = tileBlocks != kBlocksPerSingleTile && encoderHardwareDispatch(numTickets, resident, floatType, tileBlocks);
   uint16_t* spill = nullptr;
@@ -1093,24 +1174,28 @@ int encodeCommon(
 #undef DGPU_STATS_SINGLE
     DGPU_HIP(hipGetLastError());
   } else if (!hist_dev) {
-    const bool accumulate = histAccumulates(B, maxSize * wordBytes, floatType == 0);
+    const bool histList = lists && plan->numHistParts != 0;
+    const bool accumulate = !histList && histAccumulates(B, maxSize * wordBytes, floatType == 0);
     dim3 grid(accumulate ? histPartsAccFor(B, maxSize * wordBytes) : histPartsFor(B, maxSize * wordBytes, floatType == 0), B);
+    if (histList) grid = dim3(plan->numHistParts);  // one workgroup per listed (element, part)
     uint32_t* histTemp = nullptr;
     if (!accumulate) {
-      DGPU_ALLOC(ht, uint32_t, arena, (size_t)B * grid.x * kNumSymbols);
+      DGPU_ALLOC(ht, uint32_t, arena, (size_t)(histList ? 1u : B) * grid.x * kNumSymbols);
       histTemp = ht;
     }
     HistFuse fuse;
+    fuse.workMap = histList ? work_dev + plan->numTiles : nullptr;
+    fuse.partBytes = histList ? plan->histPartBytes : 0u;
     uint32_t* acc = nullptr;
     int rc = arrivalCounters(lease, &fuse.arrive, &acc);
     if (rc) return rc;
     fuse.acc = accumulate ? acc : nullptr;
     n.hist = histTemp;
     n.histAcc = fuse.acc;
-    n.histParts = grid.x;
+    n.histParts = histList ? 1u : grid.x;
     fuse.norm = n;
     // bins with 32 lane slots unless a workgroup sees too little data to pay for zeroing / folding them
-    const bool smallBins = (uint64_t)maxSize * wordBytes / grid.x <= 64u * 1024u;
+    const bool smallBins = histList ? plan->histPartBytes <= 64u * 1024u : (uint64_t)maxSize * wordBytes / grid.x <= 64u * 1024u;
 #define DGPU_HIST_LAUNCH_NT(S, NT)                                                                                \
     switch (floatType) {                                                                                          \
       case 0:                                                                                                     \
@@ -1155,6 +1240,7 @@ int encodeCommon(
     e.maxTiles = maxTiles;
     e.numInBatch = B;
     e.numTickets = numTickets;
+    e.workMap = lists ? work_dev : nullptr;
     e.tileDesc = tileDesc;
     e.claims = claims;
     e.absentModulo = absentWorkgroupModulo();
@@ -1186,12 +1272,20 @@ int ansEncodeImpl(
   TempArena arena(temp_dev, tempBytes, streamLease);
   ParamLease lease;
   BatchView in, out;
+  RaggedPlan plan;
+  const uint32_t* work_dev = nullptr;
   if (hp && asStrideViews(*hp, false, &in, &out)) {
     // (nothing to upload)
   } else if (hp) {
     const uint64_t *inP = nullptr, *outP = nullptr;
     const uint32_t* sz = nullptr;
-    int rc = uploadParams(lease, stream, *hp, &inP, &outP, &sz);
+    HostParams listed;
+    const HostParams* up = hp;
+    if (planEncode(hp->sizes, 0u, maxSize, histogram_dev == nullptr, &plan, &listed.work)) {
+      listed.inPtrs = hp->inPtrs, listed.outPtrs = hp->outPtrs, listed.sizes = hp->sizes;
+      up = &listed;
+    }
+    int rc = uploadParams(lease, stream, *up, &inP, &outP, &sz, nullptr, &work_dev);
     if (rc) return rc;
     in = viewPointers(inP, sz, 0);
     out = viewPointers(outP, nullptr, 0);
@@ -1199,7 +1293,8 @@ int ansEncodeImpl(
     in = *strideIn;
     out = *strideOut;
   }
-  int rc = encodeCommon(arena, streamLease, stream, P, useChecksum != 0, B, in, out, 0, maxSize, histogram_dev, outSize_dev);
+  int rc = encodeCommon(arena, streamLease, stream, P, useChecksum != 0, B, in, out, 0, maxSize, histogram_dev, outSize_dev, 0xffffffffu,
+                        &plan, work_dev);
   if (tempUsed) *tempUsed = arena.requested();
   return rc;
 }
@@ -1220,17 +1315,26 @@ int floatCompressImpl(
   ParamLease lease;
   BatchView in, out;
   int rc = DGPU_OK;
+  RaggedPlan plan;
+  const uint32_t* work_dev = nullptr;
   if (!asStrideViews(hp, false, &in, &out)) {
     const uint64_t *inP = nullptr, *outP = nullptr;
     const uint32_t* sz = nullptr;
-    rc = uploadParams(lease, stream, hp, &inP, &outP, &sz);
+    HostParams listed;
+    const HostParams* up = &hp;
+    if (planEncode(hp.sizes, ft, maxSize, true, &plan, &listed.work)) {
+      listed.inPtrs = hp.inPtrs, listed.outPtrs = hp.outPtrs, listed.sizes = hp.sizes;
+      up = &listed;
+    }
+    rc = uploadParams(lease, stream, *up, &inP, &outP, &sz, nullptr, &work_dev);
     if (rc) return rc;
     in = viewPointers(inP, sz, 0);
     out = viewPointers(outP, nullptr, 0);
   }
 
   // No exponent plane in temp memory: the encoder splits the float words itself.
-  rc = encodeCommon(arena, streamLease, stream, P, useChecksum != 0, B, in, out, ft, maxSize, nullptr, outSize_dev);
+  rc = encodeCommon(arena, streamLease, stream, P, useChecksum != 0, B, in, out, ft, maxSize, nullptr, outSize_dev, 0xffffffffu, &plan,
+                    work_dev);
   if (tempUsed) *tempUsed = arena.requested();
   return rc;
 }
@@ -1242,6 +1346,14 @@ int floatCompressImpl(
 // Zipf bytes -1 %.  It needs enough elements to keep the eight XCDs level (16 x 8 Mi: +17 % for the decoder alone, a
 // batch of one: everything on one XCD), so small batches keep the element-major order.  -1 = this policy;
 // dgpu_debug_set_decoder_order / DGPU_DEC_ORDER force an order (tests, A/B runs).
+// blocks per decoder tile for a batch whose largest capacity has `maxBlocks` blocks: elements of up to 8 blocks:
+// 4-block workgroups, of up to 2 blocks: one wavefront (see kDecBlocksPerSmallTile)
+uint32_t decTileBlocksFor(uint32_t maxBlocks) {
+  return maxBlocks <= 1u ? kDecBlocksPerSingleTile
+      : maxBlocks <= 2u  ? kDecBlocksPerTinyTile
+      : maxBlocks <= 8u  ? kDecBlocksPerSmallTile
+                         : kDecBlocksPerTile;
+}
 std::atomic<int> g_decOrder{[] {
   const char* e = getenv("DGPU_DEC_ORDER");
   return e && *e ? atoi(e) : -1;
@@ -1305,12 +1417,26 @@ int decodeImpl(
   ParamLease lease;
   BatchView in, out;
   const uint32_t* inBytes_dev = nullptr;
+  const uint32_t* work_dev = nullptr;
+  uint32_t numListedTiles = 0;
   if (hp && asStrideViews(*hp, true, &in, &out)) {
     // (nothing to upload)
   } else if (hp) {
     const uint64_t *inP = nullptr, *outP = nullptr;
     const uint32_t* cap = nullptr;
-    int rc = uploadParams(lease, stream, *hp, &inP, &outP, &cap, &inBytes_dev);
+    // (capacities that differ widely: only the tiles inside each element's capacity are launched, see RaggedPlan)
+    HostParams listed;
+    const HostParams* up = hp;
+    {
+      const uint32_t blocks = divUp(maxCapacity, kBlockSize);
+      const uint32_t tb = decTileBlocksFor(blocks);
+      if (tb != kDecBlocksPerSingleTile && planTileList(hp->sizes, tb * kBlockSize, std::max(1u, divUp(blocks, tb)), 1u, &listed.work)) {
+        listed.inPtrs = hp->inPtrs, listed.outPtrs = hp->outPtrs, listed.sizes = hp->sizes, listed.inBytes = hp->inBytes;
+        up = &listed;
+        numListedTiles = (uint32_t)listed.work.size();
+      }
+    }
+    int rc = uploadParams(lease, stream, *up, &inP, &outP, &cap, &inBytes_dev, &work_dev);
     if (rc) return rc;
     in = viewPointers(inP, nullptr, 0);
     out = viewPointers(outP, cap, 0);
@@ -1332,12 +1458,8 @@ int decodeImpl(
     }
   }
 
-  // elements of up to 8 blocks: 4-block workgroups, of up to 2 blocks: one wavefront (see kDecBlocksPerSmallTile)
   const uint32_t maxBlocks = divUp(maxCapacity, kBlockSize);
-  const uint32_t tileBlocks = maxBlocks <= 1u ? kDecBlocksPerSingleTile
-      : maxBlocks <= 2u                       ? kDecBlocksPerTinyTile
-      : maxBlocks <= 8u                       ? kDecBlocksPerSmallTile
-                                              : kDecBlocksPerTile;
+  const uint32_t tileBlocks = decTileBlocksFor(maxBlocks);
   const uint32_t maxTiles = std::max(1u, divUp(maxBlocks, tileBlocks));
   {
     DecodeArgs d;
@@ -1351,7 +1473,13 @@ int decodeImpl(
     d.numInBatch = B;
     d.maxTiles = maxTiles;
     d.order = decodeOrder(B);
+    d.workMap = nullptr;
     dim3 grid((d.order == kDecOrderXcd ? roundUp(B, 8u) : B) * maxTiles);
+    if (work_dev && numListedTiles) {
+      d.order = kDecOrderMap;
+      d.workMap = work_dev;
+      grid = dim3(numListedTiles);
+    }
     int rc;
     if (ft == 0) rc = launchDecodeF<0>(P, d, tileBlocks, grid, stream);
     else if (ft == kFloat16) rc = launchDecodeF<kFloat16>(P, d, tileBlocks, grid, stream);
@@ -1454,6 +1582,7 @@ void dgpu_debug_set_absent_workgroups(uint32_t modulo) { g_absentModulo.store(mo
 void dgpu_debug_set_encoder_dispatch(int mode) { g_encDispatch.store(mode < 0 ? -1 : (mode != 0)); }
 void dgpu_debug_set_decoder_order(int order) { g_decOrder.store(order); }
 void dgpu_debug_set_param_cache(int on) { g_paramCacheEnabled.store(on != 0); }
+void dgpu_debug_set_work_lists(int mode) { g_workLists.store(mode < 0 ? -1 : (mode ? 1 : 0)); }
 void dgpu_set_histogram_load_policy(int mode) { g_histLoadPolicy.store(mode < 0 ? -1 : (mode != 0)); }
 int dgpu_release_graph_state(void) {
   const int n = paramCache().releaseGraphPins();
@@ -1524,7 +1653,8 @@ static size_t encodeTempBytes(uint32_t B, uint32_t maxBytes, uint32_t wordBytes,
   size_t parts = histPartsFor(B, maxBytes * wordBytes, true);
   size_t t = 0;
   t += alignUp((size_t)B * 4, kTempAlign);                                        // checksums
-  t += alignUp((size_t)B * parts * kNumSymbols * 4, kTempAlign);                  // partial histograms
+  // partial histograms: the rectangle, or the list of a batch whose elements differ widely in size (planHistList)
+  t += alignUp(std::max((size_t)B * parts, (size_t)B + kHistTargetWgsForListsRaw + 16u) * kNumSymbols * 4, kTempAlign);
   t += alignUp((size_t)B * kNumSymbols * 16, kTempAlign);                         // encoder table
   t += alignUp((size_t)B * tiles * 8, kTempAlign);                                // tile descriptors
   t += alignUp((size_t)B * tiles * 4, kTempAlign);                                // tile claim words
@@ -1922,6 +2052,8 @@ int dgpu_ans_histogram_batch_stride(
   BatchView in = viewStride(in_dev, inPerBatchStride, inPerBatchSize);
   dim3 grid(gridX(inPerBatchSize, 32 * 1024, 64), numInBatch);
   HistFuse noFuse;
+  noFuse.workMap = nullptr;
+  noFuse.partBytes = 0;
   noFuse.arrive = nullptr;
   noFuse.acc = nullptr;
   noFuse.norm = NormalizeArgs{};

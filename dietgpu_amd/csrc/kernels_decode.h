@@ -58,6 +58,7 @@ struct DecodeArgs {
   uint32_t maxTiles;       // k_ans_decode: tiles per element the 1-D grid is laid out for
   uint32_t order;          // k_ans_decode: how workgroup index -> (element, tile), see decodeTileOf
   uint32_t uniformInBytes; // != 0 (and inBytes == nullptr): every archive has this many bytes available (stride batches)
+  const uint32_t* workMap; // kDecOrderMap: [grid] element << 16 | tile, the tiles that exist (the host knows the capacities)
 };
 __device__ __forceinline__ uint64_t decodeInBytes(const DecodeArgs& a, uint32_t b) {
   return a.inBytes ? (uint64_t)a.inBytes[b] : (a.uniformInBytes ? (uint64_t)a.uniformInBytes : ~0ull);
@@ -69,9 +70,18 @@ __device__ __forceinline__ uint64_t decodeInBytes(const DecodeArgs& a, uint32_t 
 //   kDecOrderTileMajor:    w = tile * B + b -- the order the encoder wrote the archives in
 //   kDecOrderXcd:          every XCD walks ITS elements (b mod 8 == XCD) element-major: consecutive workgroups touch
 //                          eight elements, and an element's header, pdf table and descriptors stay in one XCD's L2
-constexpr uint32_t kDecOrderElementMajor = 0, kDecOrderTileMajor = 1, kDecOrderXcd = 2;
+//   kDecOrderMap:          batches whose capacities differ widely: the grid holds only the tiles inside each element's
+//                          capacity, listed by the host (a rectangle laid out for the largest element would be mostly
+//                          workgroups that start, find nothing and leave)
+constexpr uint32_t kDecOrderElementMajor = 0, kDecOrderTileMajor = 1, kDecOrderXcd = 2, kDecOrderMap = 3;
 __device__ __forceinline__ bool decodeTileOf(const DecodeArgs& a, uint32_t w, uint32_t* b, uint32_t* tile) {
   const uint32_t T = a.maxTiles, B = a.numInBatch;
+  if (a.order == kDecOrderMap) {
+    const uint32_t m = a.workMap[w];
+    *b = m >> 16;
+    *tile = m & 0xffffu;
+    return true;
+  }
   if (a.order == kDecOrderTileMajor) {
     *tile = w / B;
     *b = w - *tile * B;

@@ -107,7 +107,8 @@ struct EncodeArgs {
   const uint4* encTable;     // [B][256] from the normalisation; null for k_ans_encode_pair (builds its own from the pdf)
   uint32_t maxTiles;         // tiles per element the ticket space is laid out for
   uint32_t numInBatch;       // B
-  uint32_t numTickets;       // B * maxTiles
+  uint32_t numTickets;       // B * maxTiles, or the entries of workMap
+  const uint32_t* workMap;   // nullable: [numTickets] element << 16 | tile, the tiles that exist in tile-major order
   uint64_t* tileDesc;        // [B][maxTiles], zeroed before launch (by the normalisation step)
   uint32_t* claims;          // [maxTiles][B] tile claim words, zeroed before launch
   uint32_t absentModulo;     // test hook: workgroups with index % absentModulo == 1 start ~0.5 ms late (0 = off)
@@ -783,23 +784,32 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
     return __hip_atomic_compare_exchange_strong(a.claims + idx, &expected, me, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                 __HIP_MEMORY_SCOPE_AGENT);
   };
+  // Ticket -> (element, tile): tile-major over the B x maxTiles rectangle, or -- batches whose elements differ widely
+  // in size -- the host's list of the tiles that exist, in the same order (a.workMap: element << 16 | tile).  Claim
+  // words and descriptors are indexed by the rectangle either way.
+  auto claimIndexOf = [&](uint32_t t) -> uint32_t {
+    if (!a.workMap) return t;
+    const uint32_t m = a.workMap[t];
+    return (m & 0xffffu) * B + (m >> 16);
+  };
   bool firstOwned = false;
-  if (tid == 0 && blockIdx.x < a.numTickets) firstOwned = claimTry(blockIdx.x);
+  if (tid == 0 && blockIdx.x < a.numTickets) firstOwned = claimTry(claimIndexOf(blockIdx.x));
   if (kPersistent) {
     for (uint32_t t = blockIdx.x + (tid + 1u) * gridDim.x; t < a.numTickets; t += kThreads * gridDim.x) {
-      (void)claimTry(t);  // later tickets: result looked up when the ticket comes up
+      (void)claimTry(claimIndexOf(t));  // later tickets: result looked up when the ticket comes up
     }
   }
   // (hardware-dispatched grid: gridDim.x == numTickets, the one ticket of this workgroup is its index)
   for (uint32_t ticket0 = blockIdx.x; ticket0 < a.numTickets; ticket0 += kPersistent ? gridDim.x : a.numTickets) {
-    const uint32_t tile0 = ticket0 / B;
-    const uint32_t b = ticket0 - tile0 * B;
+    const uint32_t claim0 = claimIndexOf(ticket0);
+    const uint32_t tile0 = claim0 / B;
+    const uint32_t b = claim0 - tile0 * B;
     const uint32_t size = a.in.size(b);
     const uint32_t nb = divUp(size, kBlockSize);
     const uint32_t numTiles = divUp(nb, kTB);
     if (tile0 >= numTiles) continue;  // uniform (ragged batch)
     if (tid == 0) {
-      bool mine = (ticket0 == blockIdx.x) ? firstOwned : (claimLoad(ticket0) == me);
+      bool mine = (ticket0 == blockIdx.x) ? firstOwned : (claimLoad(claim0) == me);
       uint32_t lo = tile0 + 1u;  // empty range: the tile was taken over by somebody else
       if (mine) {
         lo = tile0;
@@ -1015,7 +1025,8 @@ template <uint32_t FT, uint32_t S, bool kNt = true>
 __global__ __launch_bounds__(256) void k_float_histogram(BatchView in, uint32_t* __restrict__ hist, uint32_t partial, HistFuse fuse) {
   __shared__ uint32_t bins[kNumSymbols * S];
   const uint32_t tid = threadIdx.x;
-  const uint32_t b = blockIdx.y;
+  const HistWork w = histWorkOf(fuse, in, FT == kFloat32 ? 4u : 2u);
+  const uint32_t b = w.b;
   histZero<S>(bins, tid);
   __syncthreads();
   uint32_t* myBins = histMine<S>(bins, tid);
@@ -1030,7 +1041,7 @@ __global__ __launch_bounds__(256) void k_float_histogram(BatchView in, uint32_t*
   uint32_t head = wordAligned ? (uint32_t)((16u - ((uintptr_t)inBytes & 15u)) & 15u) / kWordBytes : n;
   head = head < n ? head : n;
   const uint32_t numVec = (n - head) / kWordsPerVec;
-  const uint32_t stride = gridDim.x * 256u;
+  const uint32_t stride = w.parts * 256u;
   const uint4* pv = (const uint4*)(inBytes + (size_t)head * kWordBytes);
 
   auto addVec = [&](const uint4& x) {
@@ -1054,8 +1065,8 @@ __global__ __launch_bounds__(256) void k_float_histogram(BatchView in, uint32_t*
   // takes the rest), four 16-byte loads in flight per lane (the kernel is HBM-latency bound otherwise).  Parts
   // interleaved at 4 KiB -- workgroup p reading vectors p * 256 + k * parts * 256 -- cost few-large-element batches
   // 20 % (16 x 8 Mi bf16: 32 workgroups striding through one 16 MiB element, 57 us against 46).
-  const uint32_t perPart = roundUp(divUp(numVec, gridDim.x), 1024u);
-  const uint32_t vBegin = blockIdx.x * perPart < numVec ? blockIdx.x * perPart : numVec;
+  const uint32_t perPart = roundUp(divUp(numVec, w.parts), 1024u);
+  const uint32_t vBegin = w.part * perPart < numVec ? w.part * perPart : numVec;
   const uint32_t vEnd = vBegin + perPart < numVec ? vBegin + perPart : numVec;
   uint32_t v = vBegin + tid;
   for (; v + 768u < vEnd; v += 1024u) {
@@ -1069,7 +1080,7 @@ __global__ __launch_bounds__(256) void k_float_histogram(BatchView in, uint32_t*
 
   // head and tail, word by word (the whole element when the input is not even word-aligned)
   const uint32_t loose = n - numVec * kWordsPerVec;
-  for (uint32_t j = blockIdx.x * 256u + tid; j < loose; j += stride) {
+  for (uint32_t j = w.part * 256u + tid; j < loose; j += stride) {
     const uint32_t i = j < head ? j : numVec * kWordsPerVec + j;
     uint32_t c;
     if (FT == kFloat32) c = (((const uint32_t*)inBytes)[i] >> 23) & 0xffu;
@@ -1077,7 +1088,7 @@ __global__ __launch_bounds__(256) void k_float_histogram(BatchView in, uint32_t*
     histAdd<S>(myBins, c);
   }
   __syncthreads();
-  histStore(hist, partial, fuse, b, tid, histFold<S>(bins, tid));
+  histStore(hist, partial, fuse, w, tid, histFold<S>(bins, tid));
 }
 
 }  // namespace dgpu

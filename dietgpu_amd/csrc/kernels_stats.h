@@ -230,8 +230,11 @@ constexpr uint32_t kNormScratchWords = 3u * kNumSymbols + 4u;
 // `direct` (nullable): this thread's count of symbol tid, when the calling workgroup has counted the whole
 // element itself (one histogram workgroup per element: no partial histograms, no arrival counter).
 template <bool kCoherent>
+// `partials` / `numPartials` (nullable): where the element's partial histograms lie when they are not at
+// a.hist[b][a.histParts] (HistFuse::workMap).
 __device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const uint32_t b, uint32_t* scratch,
-                                                 const uint32_t* direct = nullptr) {
+                                                 const uint32_t* direct = nullptr, const uint32_t* partials = nullptr,
+                                                 uint32_t numPartials = 0) {
   uint32_t* sKeys = scratch;  // q per symbol
   uint32_t* sPdf = scratch + 2u * kNumSymbols;
   uint32_t* sWave = scratch + 3u * kNumSymbols;
@@ -266,26 +269,27 @@ __device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const u
       __hip_atomic_store(acc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero at rest
     } else {
       // sum of the per-workgroup partial histograms, up to 16 loads in flight
-      const uint32_t* hp = a.hist + (size_t)b * a.histParts * kNumSymbols + tid;
+      const uint32_t* hp = (partials ? partials : a.hist + (size_t)b * a.histParts * kNumSymbols) + tid;
+      const uint32_t histParts = partials ? numPartials : a.histParts;
       auto part = [&](uint32_t x) -> uint32_t {
         const uint32_t* q = hp + (size_t)x * kNumSymbols;
         return kCoherent ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
       };
       uint32_t x = 0;
-      for (; x + 16u <= a.histParts; x += 16u) {
+      for (; x + 16u <= histParts; x += 16u) {
         uint32_t c[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) c[k] = part(x + k);
 #pragma unroll
         for (int k = 0; k < 16; ++k) count += c[k];
       }
-      for (; x + 4u <= a.histParts; x += 4u) {
+      for (; x + 4u <= histParts; x += 4u) {
         uint32_t c[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) c[k] = part(x + k);
         count += (c[0] + c[1]) + (c[2] + c[3]);
       }
-      for (; x < a.histParts; ++x) count += part(x);
+      for (; x < histParts; ++x) count += part(x);
     }
     // :215  qProb = kProbWeight * ((float)count / (float)totalNum), truncated.
     // Explicit round-to-nearest divide and multiply: no fma contraction, no
@@ -367,7 +371,35 @@ struct HistFuse {
   uint32_t* arrive;  // [B], zero at launch
   uint32_t* acc;     // nullable: [B][256] accumulate-by-atomics mode (few, large elements), zero at launch
   NormalizeArgs norm;
+  // Batches whose elements differ widely in size (the host knows the sizes): a 1-D grid with one workgroup per
+  // (element, part) listed in workMap -- element-major, entry = element << 16 | part -- and every element cut into
+  // parts of partBytes, instead of a (parts, B) rectangle laid out for the largest element.  nullptr: the rectangle.
+  const uint32_t* workMap;
+  uint32_t partBytes;
 };
+
+// Which (element, part of how many) a histogram workgroup counts, and where its partial histogram goes.
+struct HistWork {
+  uint32_t b, part, parts, slot;
+};
+__device__ __forceinline__ HistWork histWorkOf(const HistFuse& f, const BatchView& in, uint32_t wordBytes) {
+  HistWork w;
+  if (f.workMap) {
+    const uint32_t m = f.workMap[blockIdx.x];
+    w.b = m >> 16;
+    w.part = m & 0xffffu;
+    const uint64_t bytes = (uint64_t)in.size(w.b) * wordBytes;
+    const uint32_t parts = (uint32_t)((bytes + f.partBytes - 1u) / f.partBytes);
+    w.parts = parts ? parts : 1u;
+    w.slot = blockIdx.x;  // (the parts of an element are consecutive workgroups)
+  } else {
+    w.b = blockIdx.y;
+    w.part = blockIdx.x;
+    w.parts = gridDim.x;
+    w.slot = blockIdx.y * gridDim.x + blockIdx.x;
+  }
+  return w;
+}
 
 // ---------------------------------------------------------------------------
 // Histogram bins in LDS.  Entropy-coder inputs are skewed (one exponent value
@@ -427,19 +459,20 @@ __device__ __forceinline__ void histAdd4(uint32_t* mine, uint32_t x) {
 // (no atomics, no zero-initialisation needed; the normalisation adds the parts up).  Otherwise it adds
 // them atomically into hist[b][256], which must have been zeroed.  With f.arrive set (partial mode
 // only) the last workgroup of the element to get here also normalises it.
-__device__ __forceinline__ void histStore(uint32_t* __restrict__ hist, uint32_t partial, const HistFuse& f, uint32_t b, uint32_t tid, uint32_t sum) {
+__device__ __forceinline__ void histStore(uint32_t* __restrict__ hist, uint32_t partial, const HistFuse& f, const HistWork& w, uint32_t tid, uint32_t sum) {
+  const uint32_t b = w.b;
   if (!partial) {
     if (sum) atomicAdd(&hist[b * kNumSymbols + tid], sum);
     return;
   }
-  uint32_t* slot = &hist[((size_t)b * gridDim.x + blockIdx.x) * kNumSymbols + tid];
+  uint32_t* slot = &hist[(size_t)w.slot * kNumSymbols + tid];
   if (!f.arrive) {
     *slot = sum;
     return;
   }
   __shared__ uint32_t sLast;
   __shared__ __attribute__((aligned(16))) uint32_t sScratch[kNormScratchWords];
-  if (gridDim.x == 1u) {
+  if (w.parts == 1u) {
     // the only histogram workgroup of its element (batches of small elements): it holds the complete counts in
     // registers and normalises right away -- no partial histogram through memory, no arrival counter
     normalizeElement<true>(f.norm, b, sScratch, &sum);
@@ -456,12 +489,13 @@ __device__ __forceinline__ void histStore(uint32_t* __restrict__ hist, uint32_t 
   __syncthreads();
   if (tid == 0) {
     const uint32_t prev = __hip_atomic_fetch_add(&f.arrive[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    sLast = (prev + 1u == gridDim.x) ? 1u : 0u;
+    sLast = (prev + 1u == w.parts) ? 1u : 0u;
   }
   __syncthreads();
   if (sLast) {  // uniform
     if (tid == 0) __hip_atomic_store(&f.arrive[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    normalizeElement<true>(f.norm, b, sScratch);
+    if (f.workMap) normalizeElement<true>(f.norm, b, sScratch, nullptr, hist + (size_t)(w.slot - w.part) * kNumSymbols, w.parts);
+    else normalizeElement<true>(f.norm, b, sScratch);
   }
 }
 
@@ -469,7 +503,8 @@ template <uint32_t S, bool kNt = true>
 __global__ __launch_bounds__(256) void k_histogram(BatchView in, uint32_t* __restrict__ hist, uint32_t partial, HistFuse fuse) {
   __shared__ uint32_t bins[kNumSymbols * S];
   const uint32_t tid = threadIdx.x;
-  const uint32_t b = blockIdx.y;
+  const HistWork w = histWorkOf(fuse, in, 1u);
+  const uint32_t b = w.b;
   histZero<S>(bins, tid);
   __syncthreads();
 
@@ -484,12 +519,12 @@ __global__ __launch_bounds__(256) void k_histogram(BatchView in, uint32_t* __res
   const uint32_t numVec = remaining / 16u;
   const uint4* pv = (const uint4*)(p + head);
 
-  if (blockIdx.x == 0 && tid < head) histAdd<S>(myBins, p[tid]);
+  if (w.part == 0 && tid < head) histAdd<S>(myBins, p[tid]);
 
   // Every workgroup streams ONE contiguous part of the element (whole 16 KiB steps; the last part takes the rest), four
   // 16-byte loads in flight per lane (the kernel is HBM-latency bound otherwise); see k_float_histogram.
-  const uint32_t perPart = roundUp(divUp(numVec, gridDim.x), 1024u);
-  const uint32_t vBegin = blockIdx.x * perPart < numVec ? blockIdx.x * perPart : numVec;
+  const uint32_t perPart = roundUp(divUp(numVec, w.parts), 1024u);
+  const uint32_t vBegin = w.part * perPart < numVec ? w.part * perPart : numVec;
   const uint32_t vEnd = vBegin + perPart < numVec ? vBegin + perPart : numVec;
   uint32_t i = vBegin + tid;
   for (; i + 768u < vEnd; i += 1024u) {
@@ -507,13 +542,13 @@ __global__ __launch_bounds__(256) void k_histogram(BatchView in, uint32_t* __res
     histAdd4<S>(myBins, v.w);
   }
 
-  if (blockIdx.x == 0) {
+  if (w.part == 0) {
     uint32_t t = numVec * 16u + tid;
     if (t < remaining) histAdd<S>(myBins, p[head + t]);
   }
   __syncthreads();
 
-  histStore(hist, partial, fuse, b, tid, histFold<S>(bins, tid));
+  histStore(hist, partial, fuse, w, tid, histFold<S>(bins, tid));
 }
 
 // ---------------------------------------------------------------------------

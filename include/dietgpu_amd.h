@@ -66,7 +66,7 @@ const char* dgpu_version(void);
 /* Bumped whenever an entry point of this header is added, removed or changes its meaning.  Code that is built
  * separately against this header (the tensor-op library of this repository, a cgo / JNI binding) compares the value it was compiled with
  * against the library it finds at run time, so that a stale build fails at load instead of inside a call. */
-#define DGPU_ABI_VERSION 5u
+#define DGPU_ABI_VERSION 6u
 uint32_t dgpu_abi_version(void);
 /* Text of the last error on the calling thread (HIP error string, failed
  * precondition).  The reference aborts through glog CHECK instead. */
@@ -336,6 +336,14 @@ void dgpu_debug_set_encoder_dispatch(int mode);
  * ansDecodeBatch, GpuANSDecode.cuh:299-403) take the (element, tile) pairs.  -1 (default): the library decides per
  * call; 0: element-major; 1: tile-major; 2: every XCD walks its own elements.  Outputs are identical either way. */
 void dgpu_debug_set_decoder_order(int order);
+
+/* Measurement / test hook: batches whose elements differ widely in size (the tensors of a model in one call).  The
+ * grids of upstream's kernels -- and this library's -- are rectangles laid out for the largest element
+ * (GpuANSEncode.cuh:692-760, GpuANSDecode.cuh:299-403: maxSize x numInBatch); here the sizes arrive as host arrays, so
+ * for a batch in which at least half of that rectangle would be empty the host lists the tiles and histogram parts
+ * that exist and the kernels work through the lists.  -1 (default): that policy; 0: always the rectangles; 1: the
+ * lists for every pointer-array call whose sizes differ.  Archives and outputs are byte-identical either way. */
+void dgpu_debug_set_work_lists(int mode);
 
 /* Measurement hook: 0 makes every pointer-array call upload its parameter block
  * (no reuse of blocks already resident on the device); 1 (default) restores the

@@ -1849,3 +1849,89 @@ def test_small_elements_with_more_spilling_wavefronts_than_pool_slots(dg, ft, pr
                                   prob_bits=prob_bits)
     assert status.cpu().numpy().all()
     assert (tensor_to_words(ft, out) == flat).all()
+
+
+# ----------------------------------------------------------------- batches whose elements differ widely in size
+def _mixed_size_batch(rng, ft, big, count):
+    """One element of `big` symbols next to `count` small ones (empty, below a block, a few blocks)."""
+    ns = [big] + [int(n) for n in rng.integers(0, 3 * 4096, count)]
+    ns[3], ns[7] = 0, 4096
+    rng.shuffle(ns)
+    if ft == 0:
+        return ns, [np.ascontiguousarray(refgen.generate_symbols(max(n, 1), 30.0 + i)[:n] if i % 4 else
+                                         rng.integers(0, 256, n, dtype=np.uint8)) for i, n in enumerate(ns)]
+    dt = np.uint32 if ft == O.FLOAT32 else np.uint16
+    return ns, [np.ascontiguousarray(refgen.generate_floats(ft, max(n, 1))[:n] if i % 4 else
+                                     rng.integers(0, 1 << (8 * dt().itemsize), n, dtype=np.uint64).astype(dt), dt) for i, n in enumerate(ns)]
+
+
+@pytest.mark.parametrize("mode", [-1, 0, 1])
+@pytest.mark.parametrize("ft", [0, O.BFLOAT16, O.FLOAT32])
+def test_batches_of_widely_different_sizes(dg, ft, mode):
+    # The kernels' grids are rectangles laid out for the largest element; when at least half of such a rectangle would
+    # be empty the host lists the tiles and histogram parts that exist and the kernels work through the lists
+    # (capi.hip, RaggedPlan).  mode -1: the library's policy (lists here: 1 element of 70 blocks next to 60 of < 3),
+    # 0: the rectangles, 1: lists forced -- also on the batches of the ragged fuzz test, which the policy would leave
+    # to the rectangles.  Archives byte-identical to the oracle in every mode, with checksums, decoded through the
+    # same mode into capacities larger than the sizes (the decoder's list comes from the capacities).
+    L = dg.lib()
+    L.dgpu_debug_set_work_lists(mode)
+    try:
+        rng = np.random.default_rng(8800 + ft)
+        ns, ws = _mixed_size_batch(rng, ft, 70 * 4096 + 1234, 60)
+        if ft == 0:
+            got = gpu_ans_encode(dg, ws, 10, True)
+            for w, g in zip(ws, got):
+                want = O.ans_encode(w, 10, use_checksum=True)
+                assert g.size == want.size and not (g != want).any(), ("raw", w.size)
+            outs, status, osz = gpu_ans_decode(dg, got, [n + (i % 5) * 1000 for i, n in enumerate(ns)], 10, True)
+            assert status.all() and osz.tolist() == ns and all((o[: w.size] == w).all() for o, w in zip(outs, ws))
+        else:
+            ts = [words_to_tensor(ft, w) for w in ws]
+            comp, sizes, _ = dg.compress_data(True, ts, True)
+            hs, hc = sizes.cpu().numpy(), comp.cpu().numpy()
+            arch = []
+            for i, w in enumerate(ws):
+                want = O.float_compress(ft, w, 10, use_checksum=True)
+                assert hs[i] == want.size and not (hc[i, : hs[i]] != want).any(), (ft, w.size)
+                arch.append(comp[i, : hs[i]].clone())
+            outs = [torch.empty((n + (i % 5) * 1000,), dtype=FT_DTYPE[ft], device=DEV) for i, n in enumerate(ns)]
+            status = torch.zeros((len(ns),), dtype=torch.uint8, device=DEV)
+            osz = torch.zeros((len(ns),), dtype=torch.int32, device=DEV)
+            dg.decompress_data(True, arch, outs, True, None, status, osz)
+            assert status.cpu().numpy().all() and osz.cpu().tolist() == ns
+            assert all((tensor_to_words(ft, o[:n]) == w).all() for o, n, w in zip(outs, ns, ws))
+        if mode == 1 and ft == 0:
+            test_fuzz_ragged_batches(dg, 2)
+            test_encoder_with_absent_workgroups(dg, 3)
+            test_decode_ring_slices_and_batches(dg)
+        if mode == 1 and ft == O.BFLOAT16:
+            test_ragged_batches_of_small_elements(dg, 10, 4)
+            test_partial_last_blocks_at_every_row_count(dg, 3)
+            test_decoder_rejects_truncated_archives(dg)
+    finally:
+        L.dgpu_debug_set_work_lists(-1)
+
+
+def test_one_large_tensor_among_many_small_ones(dg):
+    # the shape tools/ragged_probe.py times (5.7 ms per compress call on the rectangles): one 8 Mi-word bf16 tensor and
+    # 255 tensors of 2048 words; round trip, sizes, and the same archives from lists and rectangles
+    g = torch.Generator(device=DEV).manual_seed(77)
+    ts = [torch.randn(8 << 20, generator=g, device=DEV).to(torch.bfloat16)]
+    ts += [torch.randn(2048, generator=g, device=DEV).to(torch.bfloat16) for _ in range(255)]
+    L = dg.lib()
+    comps = []
+    for mode in (-1, 0):
+        L.dgpu_debug_set_work_lists(mode)
+        try:
+            comp, sizes, _ = dg.compress_data(True, ts, True)
+            rows = [comp[i, : int(s)].clone() for i, s in enumerate(sizes.cpu().tolist())]
+            outs = [torch.empty_like(t) for t in ts]
+            status = torch.zeros((len(ts),), dtype=torch.uint8, device=DEV)
+            dg.decompress_data(True, rows, outs, True, None, status)
+            assert status.cpu().numpy().all()
+            assert all(torch.equal(a.view(torch.int16), b.view(torch.int16)) for a, b in zip(ts, outs))
+            comps.append(rows)
+        finally:
+            L.dgpu_debug_set_work_lists(-1)
+    assert all(torch.equal(a, b) for a, b in zip(*comps))

@@ -1,0 +1,36 @@
+"""What a batch whose elements differ widely in size costs: the grids are laid out for the largest element (as upstream's
+are), so the workgroups beyond a small element's end start, find nothing and leave.  One large bf16 tensor alone, next to
+255 small ones, and the small ones alone.  Usage (GPU box): python tools/ragged_probe.py"""
+import sys, time, torch
+sys.path.insert(0, ".")
+import dietgpu_amd as dg
+dg.load_torch_ops()
+dev = "cuda:0"
+g = torch.Generator(device=dev).manual_seed(5)
+
+
+def rate(ts, reps=50):
+    comp, sizes, _ = dg.compress_data(True, ts, False)
+    rows = [comp[i] for i in range(len(ts))]
+    outs = [torch.empty_like(t) for t in ts]
+    dg.decompress_data(True, rows, outs, False)
+    assert all(torch.equal(a.view(torch.int16), b.view(torch.int16)) for a, b in zip(ts, outs))
+    temp = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+    res = []
+    for fn in (lambda: dg.compress_data(True, ts, False, temp, comp, sizes), lambda: dg.decompress_data(True, rows, outs, False, temp)):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        res.append((time.perf_counter() - t0) / reps * 1e6)
+    return res
+
+
+for big_n in (32 << 20, 4 << 20):
+    big = torch.randn(big_n, generator=g, device=dev).to(torch.bfloat16)
+    for small_n in (2048, 20000):
+        small = [torch.randn(small_n, generator=g, device=dev).to(torch.bfloat16) for _ in range(255)]
+        a, b, c = rate([big]), rate([big] + small), rate(small)
+        print(f"1 x {big_n} + 255 x {small_n} bf16: compress / decompress us   large alone {a[0]:8.1f} {a[1]:8.1f}   together {b[0]:8.1f} {b[1]:8.1f}   small alone {c[0]:8.1f} {c[1]:8.1f}")
