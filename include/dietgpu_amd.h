@@ -340,7 +340,7 @@ void dgpu_debug_set_decoder_order(int order);
 /* Measurement / test hook: batches whose elements differ widely in size (the tensors of a model in one call).  The
  * grids of upstream's kernels -- and this library's -- are rectangles laid out for the largest element
  * (GpuANSEncode.cuh:692-760, GpuANSDecode.cuh:299-403: maxSize x numInBatch); here the sizes arrive as host arrays, so
- * for a batch in which at least half of that rectangle would be empty the host lists the tiles and histogram parts
+ * for a batch in which at least a fifth of that rectangle would be empty the host lists the tiles and histogram parts
  * that exist and the kernels work through the lists.  -1 (default): that policy; 0: always the rectangles; 1: the
  * lists for every pointer-array call whose sizes differ.  Archives and outputs are byte-identical either way. */
 void dgpu_debug_set_work_lists(int mode);

@@ -1868,7 +1868,7 @@ def _mixed_size_batch(rng, ft, big, count):
 @pytest.mark.parametrize("mode", [-1, 0, 1])
 @pytest.mark.parametrize("ft", [0, O.BFLOAT16, O.FLOAT32])
 def test_batches_of_widely_different_sizes(dg, ft, mode):
-    # The kernels' grids are rectangles laid out for the largest element; when at least half of such a rectangle would
+    # The kernels' grids are rectangles laid out for the largest element; when at least a fifth of such a rectangle would
     # be empty the host lists the tiles and histogram parts that exist and the kernels work through the lists
     # (capi.hip, RaggedPlan).  mode -1: the library's policy (lists here: 1 element of 70 blocks next to 60 of < 3),
     # 0: the rectangles, 1: lists forced -- also on the batches of the ragged fuzz test, which the policy would leave

@@ -34,3 +34,10 @@ for big_n in (32 << 20, 4 << 20):
         small = [torch.randn(small_n, generator=g, device=dev).to(torch.bfloat16) for _ in range(255)]
         a, b, c = rate([big]), rate([big] + small), rate(small)
         print(f"1 x {big_n} + 255 x {small_n} bf16: compress / decompress us   large alone {a[0]:8.1f} {a[1]:8.1f}   together {b[0]:8.1f} {b[1]:8.1f}   small alone {c[0]:8.1f} {c[1]:8.1f}")
+
+# sizes that merely vary (uniform in [1/16, 1] of 1 Mi words; 10 % / 30 % / 60 % of the rectangle empty)
+for lo in (0.85, 0.5, 1.0 / 16):
+    ns = [int(n) for n in torch.randint(int(lo * (1 << 20)), 1 << 20, (256,), generator=torch.Generator().manual_seed(3)).tolist()]
+    ts = [torch.randn(n, generator=g, device=dev).to(torch.bfloat16) for n in ns]
+    a = rate(ts)
+    print(f"256 tensors of {lo:.2f} .. 1 Mi words bf16 ({sum(ns) * 2 / 1e6:.0f} MB): compress / decompress us {a[0]:8.1f} {a[1]:8.1f}")
