@@ -950,8 +950,9 @@ bool encoderHardwareDispatch(uint32_t numTickets, uint32_t resident, uint32_t fl
 // for the two size classes on their own).  The host knows the sizes (they arrive as host arrays), so for such a batch
 // it lists the work that exists -- HostParams::work, uploaded with the pointers -- and the kernels take their
 // (element, tile / part) from the list instead of from the rectangle:
-//   * tiles (encoder, decoder): tile-major, as the rectangle's ticket order -- a tile's predecessor has a smaller
-//     ticket -- with the elements of a round in descending size;
+//   * tiles: the encoder's element by element, the large elements first (a tile's predecessor has the ticket before
+//     its own, and descriptors and claim words exist for the listed tiles only); the decoder's, which do not depend on
+//     one another, tile-major;
 //   * histogram parts: every element cut into parts of histPartBytes (chosen for the usual number of workgroups over
 //     the WHOLE batch), element-major, so that an element's partial histograms are consecutive.
 // Used when at least a fifth of the rectangle's tiles do not exist (256 bf16 tensors of 0.06 .. 1 Mi words: compress
@@ -961,8 +962,10 @@ inline uint64_t divUp64(uint64_t a, uint64_t b) { return (a + b - 1u) / b; }
 inline uint64_t roundUp64(uint64_t a, uint64_t b) { return divUp64(a, b) * b; }
 struct RaggedPlan {
   bool use = false;
-  uint32_t numTiles = 0;      // entries of the tile list, first in HostParams::work
-  uint32_t numHistParts = 0;  // entries of the histogram list behind it (encode only)
+  // HostParams::work of an encode call: [numTiles] x {element << 16 | tile}, [numHistParts] x {element << 16 | part},
+  // [B] x {the element's first ticket = index of its first descriptor and claim word}
+  uint32_t numTiles = 0;
+  uint32_t numHistParts = 0;
   uint32_t histPartBytes = 0;
 };
 std::atomic<int> g_workLists{[] {
@@ -970,7 +973,11 @@ std::atomic<int> g_workLists{[] {
   return e && *e ? atoi(e) : -1;
 }()};
 // tiles of `tileSymbols` symbols; minTiles: 1 where an element without symbols still needs its first tile (decode)
-bool planTileList(const std::vector<uint32_t>& sizes, uint32_t tileSymbols, uint32_t maxTiles, uint32_t minTiles, std::vector<uint32_t>* work) {
+// elementMajor (encoder): an element's tiles are consecutive -- descriptors and claim words are then indexed by the
+// ticket -- elements in descending size (the large ones start first, the small ones fill the end); *tileBase receives
+// each element's first ticket.  Otherwise (decoder: no dependence between tiles) tile-major.
+bool planTileList(const std::vector<uint32_t>& sizes, uint32_t tileSymbols, uint32_t maxTiles, uint32_t minTiles, std::vector<uint32_t>* work,
+                  std::vector<uint32_t>* tileBase = nullptr) {
   const int mode = g_workLists.load();
   const size_t B = sizes.size();
   if (mode == 0 || B == 0 || B > 65535u || maxTiles > 65536u || tileSymbols == 0) return false;
@@ -985,9 +992,19 @@ bool planTileList(const std::vector<uint32_t>& sizes, uint32_t tileSymbols, uint
   std::vector<uint32_t> order(B);
   for (size_t b = 0; b < B; ++b) order[b] = (uint32_t)b;
   std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return tiles[x] > tiles[y]; });
-  work->reserve(work->size() + (size_t)total);
-  for (uint32_t r = 0; r < maxTiles; ++r) {
-    for (size_t i = 0; i < B && tiles[order[i]] > r; ++i) work->push_back((order[i] << 16) | r);
+  const size_t first = work->size();
+  work->reserve(first + (size_t)total);
+  if (tileBase) {
+    tileBase->assign(B, 0u);
+    for (size_t i = 0; i < B; ++i) {
+      const uint32_t b = order[i];
+      (*tileBase)[b] = (uint32_t)(work->size() - first);
+      for (uint32_t r = 0; r < tiles[b]; ++r) work->push_back((b << 16) | r);
+    }
+  } else {
+    for (uint32_t r = 0; r < maxTiles; ++r) {
+      for (size_t i = 0; i < B && tiles[order[i]] > r; ++i) work->push_back((order[i] << 16) | r);
+    }
   }
   return true;
 }
@@ -1010,10 +1027,12 @@ void planHistList(const std::vector<uint32_t>& sizes, uint32_t wordBytes, bool r
 bool planEncode(const std::vector<uint32_t>& sizes, uint32_t floatType, uint32_t maxSize, bool needHist, RaggedPlan* plan, std::vector<uint32_t>* work) {
   const uint32_t tileBlocks = encTileBlocksFor(maxSize);
   if (tileBlocks == kBlocksPerSingleTile) return false;  // single-block batches: one wavefront per element, nothing to list
-  if (!planTileList(sizes, tileBlocks * kBlockSize, tilesFor(maxSize), 0u, work)) return false;
+  std::vector<uint32_t> tileBase;
+  if (!planTileList(sizes, tileBlocks * kBlockSize, tilesFor(maxSize), 0u, work, &tileBase)) return false;
   plan->use = true;
   plan->numTiles = (uint32_t)work->size();
   if (needHist) planHistList(sizes, floatType ? floatWordBytes(floatType) : 1u, floatType == 0, plan, work);
+  work->insert(work->end(), tileBase.begin(), tileBase.end());
   return true;
 }
 
@@ -1103,15 +1122,16 @@ int encodeCommon(
     DGPU_ALLOC(tb, uint4, arena, (size_t)B * kNumSymbols);
     table = tb;
   }
-  DGPU_ALLOC(tileDesc, uint64_t, arena, (size_t)B * std::max(maxTiles, 1u));
-  DGPU_ALLOC(claims, uint32_t, arena, (size_t)B * std::max(maxTiles, 1u));
+  // (work lists: descriptors and claim words for the tiles that exist only)
+  const bool lists = plan && plan->use && work_dev;
+  DGPU_ALLOC(tileDesc, uint64_t, arena, lists ? std::max<size_t>(plan->numTiles, 1u) : (size_t)B * std::max(maxTiles, 1u));
+  DGPU_ALLOC(claims, uint32_t, arena, lists ? std::max<size_t>(plan->numTiles, 1u) : (size_t)B * std::max(maxTiles, 1u));
 
   // The encoder's grid.  `resident` = the workgroups of the kernel that fit on the chip at once.  8-block float tiles
   // run as `resident` persistent workgroups that walk the tickets with a static map; raw bytes and float tiles of 2 / 4
   // blocks run one workgroup per tile when there are more tiles than that, dispatched by the hardware in ticket order
   // (encoderHardwareDispatch); k_ans_encode_pair always runs one workgroup per pair.  Spill slots (float inputs):
   // [resident][slots per workgroup] -- a persistent workgroup's own, or a pool handed out through spillFlags.
-  const bool lists = plan && plan->use && work_dev;
   const uint32_t numTickets = lists ? plan->numTiles : B * maxTiles;
   const uint32_t resident = maxTiles > 0 ? encodeGrid(P, floatType, tileBlocks, numTickets) : 0u;
   const bool hwDispatch = tileBlocks != kBlocksPerSingleTile && encoderHardwareDispatch(numTickets, resident, floatType, tileBlocks);
@@ -1154,6 +1174,8 @@ int encodeCommon(
   n.maxTiles = maxTiles;
   n.claims = claims;
   n.numInBatch = B;
+  n.tileBase = lists ? work_dev + (size_t)plan->numTiles + plan->numHistParts : nullptr;
+  n.tileSymbols = tileBlocks * kBlockSize;
 
   if (!hist_dev && tileBlocks == kBlocksPerSingleTile && maxTiles > 0 && floatType != kFloat32) {
     // batches of single-block elements: one wavefront counts and normalises an element (kernels_pairs.h); no partial
@@ -1185,7 +1207,7 @@ int encodeCommon(
       histTemp = ht;
     }
     HistFuse fuse;
-    fuse.workMap = histList ? work_dev + plan->numTiles : nullptr;
+    fuse.workMap = histList ? work_dev + (size_t)plan->numTiles : nullptr;
     fuse.partBytes = histList ? plan->histPartBytes : 0u;
     uint32_t* acc = nullptr;
     int rc = arrivalCounters(lease, &fuse.arrive, &acc);
@@ -2087,6 +2109,8 @@ int dgpu_ans_calc_weights(
   n.maxTiles = 0;
   n.claims = nullptr;
   n.numInBatch = numInBatch;
+  n.tileBase = nullptr;
+  n.tileSymbols = 0;
   hipLaunchKernelGGL(k_normalize, dim3(numInBatch), dim3(256), 0, (hipStream_t)stream, n);
   DGPU_HIP(hipGetLastError());
   return DGPU_OK;

@@ -108,9 +108,9 @@ struct EncodeArgs {
   uint32_t maxTiles;         // tiles per element the ticket space is laid out for
   uint32_t numInBatch;       // B
   uint32_t numTickets;       // B * maxTiles, or the entries of workMap
-  const uint32_t* workMap;   // nullable: [numTickets] element << 16 | tile, the tiles that exist in tile-major order
-  uint64_t* tileDesc;        // [B][maxTiles], zeroed before launch (by the normalisation step)
-  uint32_t* claims;          // [maxTiles][B] tile claim words, zeroed before launch
+  const uint32_t* workMap;   // nullable: [numTickets] element << 16 | tile: the tiles that exist, element by element
+  uint64_t* tileDesc;        // [B][maxTiles] (workMap: [numTickets]), zeroed before launch (by the normalisation step)
+  uint32_t* claims;          // [maxTiles][B] (workMap: [numTickets]) tile claim words, zeroed before launch
   uint32_t absentModulo;     // test hook: workgroups with index % absentModulo == 1 start ~0.5 ms late (0 = off)
   uint16_t* spill;           // kSpill kernels only.  Persistent grids (k_ans_encode, 8-block float tiles): [gridDim.x][blocks
                              // per tile][encSpillSlotWords(P)], a workgroup's slots are its own.  Hardware-dispatched grids
@@ -785,36 +785,39 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
                                                 __HIP_MEMORY_SCOPE_AGENT);
   };
   // Ticket -> (element, tile): tile-major over the B x maxTiles rectangle, or -- batches whose elements differ widely
-  // in size -- the host's list of the tiles that exist, in the same order (a.workMap: element << 16 | tile).  Claim
-  // words and descriptors are indexed by the rectangle either way.
-  auto claimIndexOf = [&](uint32_t t) -> uint32_t {
+  // in size -- the host's list of the tiles that exist (a.workMap: element << 16 | tile), element by element.  Either
+  // way a tile's predecessor has a smaller ticket and the claim word of a ticket is indexed by the ticket; under a
+  // list the descriptors are too (an element's are consecutive), so only tiles that exist need either.
+  // (One path for both forms -- a list entry is turned into the rectangle's index and divided like a ticket: two
+  // assignments under a branch instead cost the float encoders a register they do not have.)
+  auto rectIndexOf = [&](uint32_t t) -> uint32_t {
     if (!a.workMap) return t;
     const uint32_t m = a.workMap[t];
     return (m & 0xffffu) * B + (m >> 16);
   };
   bool firstOwned = false;
-  if (tid == 0 && blockIdx.x < a.numTickets) firstOwned = claimTry(claimIndexOf(blockIdx.x));
+  if (tid == 0 && blockIdx.x < a.numTickets) firstOwned = claimTry(blockIdx.x);
   if (kPersistent) {
     for (uint32_t t = blockIdx.x + (tid + 1u) * gridDim.x; t < a.numTickets; t += kThreads * gridDim.x) {
-      (void)claimTry(claimIndexOf(t));  // later tickets: result looked up when the ticket comes up
+      (void)claimTry(t);  // later tickets: result looked up when the ticket comes up
     }
   }
   // (hardware-dispatched grid: gridDim.x == numTickets, the one ticket of this workgroup is its index)
   for (uint32_t ticket0 = blockIdx.x; ticket0 < a.numTickets; ticket0 += kPersistent ? gridDim.x : a.numTickets) {
-    const uint32_t claim0 = claimIndexOf(ticket0);
-    const uint32_t tile0 = claim0 / B;
-    const uint32_t b = claim0 - tile0 * B;
+    const uint32_t rect0 = rectIndexOf(ticket0);
+    const uint32_t tile0 = rect0 / B;
+    const uint32_t b = rect0 - tile0 * B;
     const uint32_t size = a.in.size(b);
     const uint32_t nb = divUp(size, kBlockSize);
     const uint32_t numTiles = divUp(nb, kTB);
     if (tile0 >= numTiles) continue;  // uniform (ragged batch)
     if (tid == 0) {
-      bool mine = (ticket0 == blockIdx.x) ? firstOwned : (claimLoad(claim0) == me);
+      bool mine = (ticket0 == blockIdx.x) ? firstOwned : (claimLoad(ticket0) == me);
       uint32_t lo = tile0 + 1u;  // empty range: the tile was taken over by somebody else
       if (mine) {
         lo = tile0;
         while (lo > 0u) {
-          const uint32_t idx = (lo - 1u) * B + b;
+          const uint32_t idx = a.workMap ? ticket0 - tile0 + (lo - 1u) : (lo - 1u) * B + b;
           uint32_t p = claimLoad(idx);
           for (int spin = 0; p == 0u && spin < 4; ++spin) {  // give a running owner's claim time to land
             __builtin_amdgcn_s_sleep(32);
@@ -930,7 +933,7 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
         const uint32_t aggregate = __shfl(incl, kTB - 1, 64);
         if (lane < kTB) sh->localOff[lane] = incl - myPadded;
 
-        uint64_t* desc = a.tileDesc + (size_t)b * a.maxTiles;
+        uint64_t* desc = a.tileDesc + (a.workMap ? (size_t)(ticket0 - tile0) : (size_t)b * a.maxTiles);
         if (lane == 0) {
           __hip_atomic_store(&desc[tile], kDescAggregate | (tileFailed ? kDescFailed : 0ull) | (uint64_t)aggregate,
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -192,6 +192,10 @@ struct NormalizeArgs {
   uint32_t maxTiles;
   uint32_t* claims;          // [maxTiles][numInBatch] nullable (encoder's tile claim words)
   uint32_t numInBatch;
+  // batches whose elements differ widely in size (EncodeArgs::workMap): descriptors and claim words exist for the tiles
+  // that exist only, element by element; element b's begin at tileBase[b], it has ceil(size / tileSymbols) of them
+  const uint32_t* tileBase;  // nullable: [numInBatch]
+  uint32_t tileSymbols;
 };
 
 // The static part of the ANS archive header of element b (the fields ansEncodeCoalesce writes at
@@ -251,7 +255,13 @@ __device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const u
 
   uint32_t pdf = 0, cdf = 0;
 
-  if (a.tileDesc) {
+  if (a.tileDesc && a.tileBase) {
+    const uint32_t first = a.tileBase[b], count = divUp(total, a.tileSymbols);
+    for (uint32_t i = tid; i < count; i += 256u) {
+      a.tileDesc[(size_t)first + i] = 0;
+      if (a.claims) a.claims[(size_t)first + i] = 0;
+    }
+  } else if (a.tileDesc) {
     for (uint32_t i = tid; i < a.maxTiles; i += 256u) {
       a.tileDesc[(size_t)b * a.maxTiles + i] = 0;
       if (a.claims) a.claims[(size_t)i * a.numInBatch + b] = 0;
