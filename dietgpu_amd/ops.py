@@ -77,18 +77,15 @@ def _fast_ops(prob_bits):
 
 
 def _load_fast_ops():
-    """torch.ops.dietgpu from the in-tree op library, or False.  An op library that is OLDER than the core library it
-    links against was built from other sources (dietgpu_amd.build rebuilds both together): it is not loaded -- the
-    ctypes route serves the call -- and the op library itself refuses to load against another DGPU_ABI_VERSION."""
+    """torch.ops.dietgpu from the in-tree op library, or False.  An op library built against another version of the C
+    ABI refuses to load (it compares DGPU_ABI_VERSION with dgpu_abi_version() of the core library it finds, torch_ops.cpp):
+    the ctypes route then serves the calls.  (File times are NOT consulted: a rebuild of the core library from unchanged
+    sources, or a copy of the tree, says nothing about the sources the op library was built from.)"""
     import warnings
 
-    from .build import LIB_PATH, TORCH_LIB_PATH
+    from .build import TORCH_LIB_PATH
 
     if not os.path.exists(TORCH_LIB_PATH):
-        return False
-    if os.path.getmtime(TORCH_LIB_PATH) < os.path.getmtime(LIB_PATH) and not os.environ.get("DGPU_LIB"):
-        warnings.warn(f"{TORCH_LIB_PATH} is older than {LIB_PATH}: not loaded, the ctypes route is used "
-                      "(python -m dietgpu_amd.build rebuilds both)")
         return False
     lib()  # libdietgpu_amd.so first (the op library links against it)
     try:

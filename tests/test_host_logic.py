@@ -70,21 +70,19 @@ def test_abi_version_of_the_library_is_the_headers():
     assert dietgpu_amd.lib().dgpu_abi_version() == want
 
 
-def test_stale_op_library_is_not_loaded(tmp_path, monkeypatch):
-    # an op library older than the core library was built from other sources: dietgpu_amd.ops keeps to the ctypes route
+def test_op_library_that_does_not_load_is_not_used(tmp_path, monkeypatch):
+    # an op library that cannot be loaded -- built against another ABI version (it refuses itself, torch_ops.cpp), or
+    # damaged -- leaves dietgpu_amd.ops on the ctypes route with a warning; file times play no part
     import warnings
 
     from dietgpu_amd import build, ops
 
-    core = tmp_path / "libdietgpu_amd.so"
-    stale = tmp_path / "libdietgpu_torch.so"
-    stale.write_bytes(b"")
-    core.write_bytes(b"")
-    os.utime(stale, (1, 1))
-    monkeypatch.setattr(build, "LIB_PATH", str(core))
-    monkeypatch.setattr(build, "TORCH_LIB_PATH", str(stale))
-    monkeypatch.delenv("DGPU_LIB", raising=False)
+    broken = tmp_path / "libdietgpu_torch.so"
+    broken.write_bytes(b"not a shared object")
+    monkeypatch.setattr(build, "TORCH_LIB_PATH", str(broken))
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         assert ops._load_fast_ops() is False
-    assert any("older than" in str(x.message) for x in w)
+    assert any("could not be loaded" in str(x.message) for x in w)
+    monkeypatch.setattr(build, "TORCH_LIB_PATH", str(tmp_path / "absent.so"))
+    assert ops._load_fast_ops() is False
