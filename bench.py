@@ -164,12 +164,18 @@ class Codec:
 
     def verify(self):
         torch.cuda.synchronize()
-        if os.environ.get("DGPU_BENCH_ABLATION") == "1":
+        if ablation_run():
             return  # timing ablations of tools/ab.sh variants that produce WRONG archives by design; never a measurement
         assert bool(self.status.all().item()), "decode reported failure"
         a = self.data.view(torch.uint8)
         b = self.out.view(torch.uint8)
         assert torch.equal(a, b), "round trip is not bit-exact"
+
+
+def ablation_run():
+    """DGPU_BENCH_ABLATION=1 (tools/ab.sh timing ablations: WRONG archives by design) turns Codec.verify() off: such a
+    run's line must not claim a round trip it never checked."""
+    return os.environ.get("DGPU_BENCH_ABLATION") == "1"
 
 
 def kernel_profile(codec, steps, step_fn=None):
@@ -262,7 +268,8 @@ def compact_config_line(dg, kind, device, steps, warmup, rotate=4, batch=256, el
         "dominant_kernel": dom, "dominant_kernel_frac": table[dom]["frac"] if dom else None,
         "kernels_us": {k[2:]: v["avg_us"] for k, v in table.items()},
         "compression_ratio": round(comp_total / codec.in_bytes, 4),
-        "round_trip_bit_exact": True,
+        "round_trip_bit_exact": None if ablation_run() else True,
+        **({"ablation": True} if ablation_run() else {}),
     }
     del sets, codec, data
     torch.cuda.empty_cache()
@@ -927,7 +934,8 @@ def main():
             "roofline_by_direction": by_direction,
             "kernels": kernels,
             "kernels_one_buffer_set": kernels_warm if cold else None,
-            "round_trip_bit_exact": True,
+            "round_trip_bit_exact": None if ablation_run() else True,
+            **({"ablation": "DGPU_BENCH_ABLATION=1: the round trip was NOT checked; not a measurement"} if ablation_run() else {}),
         }
         default_line = (world == 1 and args.workload == "bf16" and args.batch == 256 and args.elems == 512 * 1024
                         and not args.prob_bits and not args.quick)

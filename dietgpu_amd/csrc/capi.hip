@@ -807,15 +807,24 @@ uint32_t numComputeUnits() {
 // spilling variant (6 workgroups per CU), raw bytes the worst-case stage (3 per CU; kernels_encode.h).
 constexpr bool encodeSpills(uint32_t ft) { return ft != 0; }
 
+// (`resident` also sizes the spill-slot pool of the hardware-dispatched float encoders, whose wavefronts hold a pair
+// of slots across their look-back wait: the pool must cover whichever form of the kernel is launched, so where both
+// forms exist the larger occupancy of the two counts -- today they compile to the same register count.)
 template <int P, uint32_t FT, uint32_t TB>
 uint32_t encodeGridPFT(uint32_t tickets) {
   static const uint32_t perCu = [] {
-    int n = 0;
+    int n = 0, m = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
             &n, (k_ans_encode<P, FT, encodeSpills(FT), TB, true>), encThreads(TB), encLdsBytes(P, encodeSpills(FT), FT, TB)) != hipSuccess || n < 1) {
       n = 1;
     }
-    return (uint32_t)n;
+    if constexpr (!(encodeSpills(FT) && TB >= kBlocksPerTile)) {  // (8-block float tiles exist in the persistent form only)
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+              &m, (k_ans_encode<P, FT, encodeSpills(FT), TB, false>), encThreads(TB), encLdsBytes(P, encodeSpills(FT), FT, TB)) != hipSuccess) {
+        m = 0;
+      }
+    }
+    return (uint32_t)std::max(n, m);
   }();
   return std::max(1u, std::min(tickets, perCu * numComputeUnits()));
 }

@@ -97,6 +97,8 @@ __host__ __device__ constexpr uint32_t encLdsBytes(int P, bool spill, uint32_t f
       + tileBlocks * 512u;                           // symbol ring, 16 rows per half-wave
 }
 
+// descriptors a lane reads per look-back step (one round trip covers 64 x this many predecessor tiles)
+constexpr uint32_t kLookbackPerLane = 1;
 constexpr uint64_t kDescAggregate = 1ull << 62;
 constexpr uint64_t kDescInclusive = 2ull << 62;
 constexpr uint64_t kDescValueMask = (1ull << 62) - 1;
@@ -939,26 +941,40 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 
-        // decoupled look-back, 64 predecessors per step
+        // decoupled look-back, 64 * kLookbackPerLane predecessors per step (lane l holds the kLookbackPerLane nearest
+        // ones beyond those of lanes < l)
         uint32_t exclusive = 0;
         bool failed = tileFailed;
         int base = (int)tile - 1;
         while (base >= 0) {
-          const int idx = base - (int)lane;
-          uint64_t d = kDescInclusive;  // virtual tile -1: inclusive prefix 0
-          if (idx >= 0) {
-            do {
-              d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if ((d >> 62) == 0) __builtin_amdgcn_s_sleep(1);
-            } while ((d >> 62) == 0);
+          uint32_t sum = 0;       // aggregates of this lane's descriptors down to (and including) its first inclusive one
+          bool sawIncl = false, sawFailed = false;
+          uint64_t d[kLookbackPerLane];
+#pragma unroll
+          for (int j = 0; j < (int)kLookbackPerLane; ++j) {  // all of the lane's loads in flight at once
+            const int idx = base - (int)(lane * kLookbackPerLane) - j;
+            d[j] = kDescInclusive;  // virtual tile -1: inclusive prefix 0
+            if (idx >= 0) d[j] = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-          const uint64_t inclMask = __ballot((d >> 62) == 2);
+#pragma unroll
+          for (int j = 0; j < (int)kLookbackPerLane; ++j) {
+            if (sawIncl) continue;  // (beyond the lane's first inclusive prefix nothing counts)
+            const int idx = base - (int)(lane * kLookbackPerLane) - j;
+            while ((d[j] >> 62) == 0) {
+              __builtin_amdgcn_s_sleep(1);
+              d[j] = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            sum += (uint32_t)d[j];
+            sawFailed = sawFailed || (d[j] & kDescFailed) != 0ull;
+            sawIncl = (d[j] >> 62) == 2;
+          }
+          const uint64_t inclMask = __ballot(sawIncl);
           const int firstIncl = inclMask ? (__ffsll((unsigned long long)inclMask) - 1) : 64;
           const bool counted = (int)lane <= firstIncl;
-          exclusive += waveReduceSum(counted ? (uint32_t)d : 0u);
-          failed = failed || __ballot(counted && (d & kDescFailed) != 0ull) != 0ull;
+          exclusive += waveReduceSum(counted ? sum : 0u);
+          failed = failed || __ballot(counted && sawFailed) != 0ull;
           if (firstIncl < 64) break;
-          base -= 64;
+          base -= 64 * (int)kLookbackPerLane;
         }
 
         const uint32_t inclusive = exclusive + aggregate;

@@ -473,15 +473,22 @@ TORCH_LIBRARY_FRAGMENT(dietgpu, m) {
       "decompress_data_simple(bool compress_as_float, Tensor[] ts_in, bool checksum=False, int? temp_mem=67108864) -> Tensor[]");
 }
 
+// The version of the C ABI this file was compiled against, and whether the ops below were registered.  Plain C symbols:
+// dietgpu_amd/ops.py compares them through ctypes after loading the library.  Nothing here throws -- torch.ops.load_library
+// is a dlopen, and a C++ exception leaving a static initialiser under dlopen ends in std::terminate, not in Python.
+extern "C" uint32_t dgpu_torch_built_abi(void) { return DGPU_ABI_VERSION; }
+static bool gOpsRegistered = false;
+extern "C" int dgpu_torch_ops_registered(void) { return gOpsRegistered ? 1 : 0; }
+// a libdietgpu_amd.so from another build of the sources than this file was compiled against: register nothing
+static bool coreLibraryMatches() { return dgpu_abi_version() == DGPU_ABI_VERSION; }
+
 TORCH_LIBRARY(dietgpu_amd, m) {
+  if (!coreLibraryMatches()) return;
   m.def("set_precision(int prob_bits) -> ()", &dietgpu_amd::set_precision);
 }
 
 TORCH_LIBRARY(dietgpu, m) {
-  // a libdietgpu_amd.so from another build of the sources than this file was compiled against: fail at load
-  TORCH_CHECK(dgpu_abi_version() == DGPU_ABI_VERSION, "libdietgpu_torch.so was built against C ABI version ",
-              DGPU_ABI_VERSION, " of dietgpu_amd.h, the libdietgpu_amd.so it found has version ", dgpu_abi_version(),
-              ": rebuild (python -m dietgpu_amd.build)");
+  if (!coreLibraryMatches()) return;  // (the schemas above stay without implementations; ops.py does not use them)
   m.impl(TORCH_SELECTIVE_NAME("dietgpu::max_float_compressed_output_size"), TORCH_FN(dietgpu_amd::max_float_compressed_output_size));
   m.impl(TORCH_SELECTIVE_NAME("dietgpu::max_float_compressed_size"), TORCH_FN(dietgpu_amd::max_float_compressed_size));
   m.impl(TORCH_SELECTIVE_NAME("dietgpu::max_any_compressed_output_size"), TORCH_FN(dietgpu_amd::max_any_compressed_output_size));
@@ -492,4 +499,5 @@ TORCH_LIBRARY(dietgpu, m) {
   m.impl(TORCH_SELECTIVE_NAME("dietgpu::decompress_data"), TORCH_FN(dietgpu_amd::decompress_data));
   m.impl(TORCH_SELECTIVE_NAME("dietgpu::decompress_data_split_size"), TORCH_FN(dietgpu_amd::decompress_data_split_size));
   m.impl(TORCH_SELECTIVE_NAME("dietgpu::decompress_data_simple"), TORCH_FN(dietgpu_amd::decompress_data_simple));
+  gOpsRegistered = true;
 }

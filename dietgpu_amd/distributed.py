@@ -605,12 +605,20 @@ class CompressedExchangePlan:
 class ExchangeHandle:
     """A step of a CompressedExchangePlan that has been enqueued but not checked.  wait() -> (output, rows that had to be
     sent uncompressed): the step's ONE device-to-host read (largest archive of all ranks, rows that decoded), the per-row
-    uncompressed fall-back if rows did not fit, and the width of the next step."""
+    uncompressed fall-back if rows did not fit, and the width of the next step.
+
+    Lifetimes and ordering (the plan owns `depth` buffer sets and hands them out round robin):
+      * the tensor wait() returns IS the buffer set's output: it is valid until that buffer set is used again, i.e.
+        until the enqueue of step k + depth -- copy it (or pass clone=True) to keep it longer;
+      * the caller's input (`shard` / `send`) must stay unchanged until wait(): the per-row fall-back reads it then;
+      * wait() may run a collective (the fall-back), so every rank must wait for its handles in the SAME order relative
+        to its other collectives -- in particular before enqueueing step k + depth: an enqueue that finds its buffer
+        set still pending finishes that step first, and does so on every rank only if every rank left it pending."""
 
     def __init__(self, plan, slot, kind, fallback):
         self.plan, self.slot, self.kind, self.fallback, self.result = plan, slot, kind, fallback, None
 
-    def wait(self):
+    def wait(self, clone=False):
         if self.result is None:
             p = self.plan
             cur = p._slot
@@ -623,6 +631,8 @@ class ExchangeHandle:
                 p._unbind()
                 p._bind(cur)
             self.slot["pending"] = None
+        if clone:  # an output of the caller's own instead of the buffer set's (valid beyond step k + depth)
+            return (self.result[0].clone(), self.result[1])
         return self.result
 
 

@@ -78,20 +78,35 @@ def _fast_ops(prob_bits):
 
 def _load_fast_ops():
     """torch.ops.dietgpu from the in-tree op library, or False.  An op library built against another version of the C
-    ABI refuses to load (it compares DGPU_ABI_VERSION with dgpu_abi_version() of the core library it finds, torch_ops.cpp):
-    the ctypes route then serves the calls.  (File times are NOT consulted: a rebuild of the core library from unchanged
-    sources, or a copy of the tree, says nothing about the sources the op library was built from.)"""
+    ABI than the core library it finds registers NO op implementations (torch_ops.cpp: nothing may throw out of a static
+    initialiser under dlopen) and says so through two plain C symbols, which are compared here: the ctypes route then
+    serves the calls.  An op library from before those symbols existed is treated the same way.  (File times are NOT
+    consulted: a rebuild of the core library from unchanged sources, or a copy of the tree, says nothing about the
+    sources the op library was built from.)"""
     import warnings
 
     from .build import TORCH_LIB_PATH
 
     if not os.path.exists(TORCH_LIB_PATH):
         return False
-    lib()  # libdietgpu_amd.so first (the op library links against it)
+    core = lib()  # libdietgpu_amd.so first (the op library links against it)
     try:
         torch.ops.load_library(TORCH_LIB_PATH)
+        handle = C.CDLL(TORCH_LIB_PATH)  # (already mapped: the same handle)
     except (OSError, RuntimeError) as e:
         warnings.warn(f"{TORCH_LIB_PATH} could not be loaded ({e}): the ctypes route is used")
+        return False
+    try:
+        handle.dgpu_torch_built_abi.restype = C.c_uint32
+        built, registered = int(handle.dgpu_torch_built_abi()), int(handle.dgpu_torch_ops_registered())
+    except AttributeError:
+        built, registered = None, 0
+    have = int(core.dgpu_abi_version())
+    if built != have or not registered:
+        warnings.warn(f"{TORCH_LIB_PATH} was built against C ABI version {built} of dietgpu_amd.h, libdietgpu_amd.so has "
+                      f"version {have}: the ctypes route is used (rebuild: python -m dietgpu_amd.build)")
+        return False
+    if not hasattr(torch.ops, "dietgpu_amd") or not hasattr(torch.ops.dietgpu_amd, "set_precision"):
         return False
     return torch.ops.dietgpu
 

@@ -86,3 +86,58 @@ def test_op_library_that_does_not_load_is_not_used(tmp_path, monkeypatch):
     assert any("could not be loaded" in str(x.message) for x in w)
     monkeypatch.setattr(build, "TORCH_LIB_PATH", str(tmp_path / "absent.so"))
     assert ops._load_fast_ops() is False
+
+
+def test_op_library_built_against_another_abi_version_registers_nothing(tmp_path):
+    # The real thing: torch_ops.cpp compiled against a header whose DGPU_ABI_VERSION is one ahead of the core library's.
+    # Loading it must not end the process (torch.ops.load_library is a dlopen: an exception leaving a static initialiser
+    # there is std::terminate), it must register no op implementation, and dietgpu_amd.ops must stay on the ctypes route.
+    import re
+    import shutil
+    import subprocess
+    import sys
+
+    import torch
+
+    from dietgpu_amd import build
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    (tmp_path / "include").mkdir()
+    (tmp_path / "a" / "csrc").mkdir(parents=True)
+    with open(os.path.join(root, "include", "dietgpu_amd.h")) as f:
+        header = f.read()
+    bumped, n = re.subn(r"#define DGPU_ABI_VERSION (\d+)u", lambda m: f"#define DGPU_ABI_VERSION {int(m.group(1)) + 1}u", header)
+    assert n == 1
+    (tmp_path / "include" / "dietgpu_amd.h").write_text(bumped)
+    shutil.copy(os.path.join(build.CSRC, "torch_ops.cpp"), tmp_path / "a" / "csrc" / "torch_ops.cpp")
+    build.build()
+    tl = os.path.dirname(torch.__file__)
+    stale = tmp_path / "libdietgpu_torch.so"
+    subprocess.check_call(
+        ["g++", "-O0", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM",
+         f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", f"-I{tl}/include",
+         f"-I{tl}/include/torch/csrc/api/include", "-I/opt/rocm/include", str(tmp_path / "a" / "csrc" / "torch_ops.cpp"),
+         "-o", str(stale), f"-L{build.LIB_DIR}", "-ldietgpu_amd", f"-L{tl}/lib", "-ltorch", "-ltorch_cpu", "-lc10",
+         "-lc10_hip", "-ltorch_hip", f"-Wl,-rpath,{build.LIB_DIR}"])
+    script = f"""
+import sys, warnings
+sys.path.insert(0, {root!r})
+import torch
+from dietgpu_amd import build, ops
+build.TORCH_LIB_PATH = {str(stale)!r}
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    got = ops._load_fast_ops()
+assert got is False, got
+assert any("C ABI version" in str(x.message) for x in w), [str(x.message) for x in w]
+assert ops._fast_ops(10) is None and ops._fast_ops(11) is None
+try:
+    torch.ops.dietgpu.max_any_compressed_size(4096)
+except (RuntimeError, NotImplementedError):
+    pass
+else:
+    raise AssertionError("an op of the mismatching library has an implementation")
+print("alive")
+"""
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "alive" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
