@@ -102,6 +102,9 @@ constexpr uint32_t kLookbackPerLane = 1;
 constexpr uint64_t kDescAggregate = 1ull << 62;
 constexpr uint64_t kDescInclusive = 2ull << 62;
 constexpr uint64_t kDescValueMask = (1ull << 62) - 1;
+constexpr uint64_t kDescFailed = 1ull << 40;  // sticky: a tile overran its stage (see k_ans_encode)
+// pause between two polls of an unpublished descriptor: 512 cycles, doubling up to 16 x 512 (see lookBackExclusive)
+constexpr uint32_t kLookbackPollPauseMax = 16;
 
 struct EncodeArgs {
   BatchView in;              // raw bytes (FT == 0) or float words (FT != 0); size(b) = symbols = bytes / words
@@ -524,7 +527,9 @@ static_assert(encGuardLimit(9, 120) + 256u <= encStageWords(9) + kEncGuardSlackW
 // `symbol index < n`.  Three VALU more per row than the full-block step, against the scalar path's one memory round
 // trip per eight rows (bf16, 256 x 530 000: encode 120 -> 112 us, 32768 x 4000: 237 -> 138 us;
 // profiles/r05_ab_partial_blocks.txt).
-template <int P, uint32_t FT, bool kFull, bool kSpill, bool kGuard = false, bool kPool = false, bool kTail = false>
+// kLdsSrc (with kFull, not kTail; k_float_compress_fused): the block's 4096 symbols already lie in LDS in natural order
+// at `ring` -- nothing is loaded or split here, chunk c is the 32 * kRows bytes at ring + c * 32 * kRows.
+template <int P, uint32_t FT, bool kFull, bool kSpill, bool kGuard = false, bool kPool = false, bool kTail = false, bool kLdsSrc = false>
 __device__ __forceinline__ uint32_t encodeRows(
     const ChunkSource<FT>& src,
     uint32_t n,                           // symbols in this half's block (0 = idle half)
@@ -541,6 +546,7 @@ __device__ __forceinline__ uint32_t encodeRows(
     SpillPool* pool = nullptr) {
   static_assert(!kPool || kSpill, "");
   static_assert(!kTail || kFull, "kTail is a mode of the chunked path");
+  static_assert(!kLdsSrc || (kFull && !kTail), "kLdsSrc is a mode of the full-block path");
   const uint32_t laneMaskLt = (1u << hl) - 1u;
   uint32_t state = kStartState;
   uint32_t outOff = 0;
@@ -633,13 +639,17 @@ __device__ __forceinline__ uint32_t encodeRows(
     constexpr uint32_t kChunkRows = ChunkSource<FT>::kRows;
     static_assert(kSymAhead > kAhead && kSymAhead <= (int)kChunkRows, "a symbol slot is reused only after its table load was issued");
     const uint32_t numChunks = kTail ? divUp(maxRows, kChunkRows) : kRowsPerBlock / kChunkRows;  // (uniform)
-    typename ChunkSource<FT>::Raw cur = kTail ? src.loadTail(0, hl, n) : src.load(0, hl);
+    typename ChunkSource<FT>::Raw cur;
+    if constexpr (!kLdsSrc) cur = kTail ? src.loadTail(0, hl, n) : src.load(0, hl);
 #pragma unroll 1
     for (uint32_t c = 0; c < numChunks; ++c) {
-      if (kTail) src.consumeTail(cur, c, hl, ring, n);
-      else src.consume(cur, c, hl, ring);
-      if (c + 1 < numChunks) cur = kTail ? src.loadTail(c + 1, hl, n) : src.load(c + 1, hl);
-      auto symAt = [&](int r) -> uint32_t { return (uint32_t)ring[r * 32 + hl]; };
+      if constexpr (!kLdsSrc) {
+        if (kTail) src.consumeTail(cur, c, hl, ring, n);
+        else src.consume(cur, c, hl, ring);
+        if (c + 1 < numChunks) cur = kTail ? src.loadTail(c + 1, hl, n) : src.load(c + 1, hl);
+      }
+      const uint8_t* chunkSyms = kLdsSrc ? ring + c * (kChunkRows * 32u) : ring;
+      auto symAt = [&](int r) -> uint32_t { return (uint32_t)chunkSyms[r * 32 + hl]; };
       auto fetchEntry = [&](uint32_t sym) -> uint4 { return ldsTableEntry(tableLds + (sym << 4)); };
       uint32_t sym[kSymAhead];
 #pragma unroll
@@ -703,6 +713,58 @@ __device__ __forceinline__ uint32_t encodeRows(
   return outOff;
 }
 
+// Decoupled look-back of a tile's first wavefront over the descriptors of the preceding tiles of its element: sums their
+// aggregates down to the nearest inclusive prefix and returns the tile's exclusive prefix (u16 words); `failed` picks up
+// the sticky failure flag of every descriptor counted.  64 * kLookbackPerLane predecessors per round trip (lane l holds
+// the kLookbackPerLane nearest ones beyond those of lanes < l).  A descriptor that has not been published is polled with
+// LONG pauses between the polls (doubling from 0.2 us to 3.4 us: a short wait stays short): the descriptors of the ~1500
+// tiles in flight share a few dozen cache lines, every poll is an L2-bypassing load of such a line and every publication a
+// write-through store to one, and with short pauses the polls of the waiting tiles are what the publications queue
+// behind (measured on MI355X, bf16, fixed pauses,
+// profiles/r06_ab_lookback_backoff_*.txt: 1 x 128 Mi encode 115.1 us with s_sleep 1, 113.3 / 110.3 / 106.0 with 8 / 32 /
+// 127; 16 x 8 Mi 122.0 -> 113.4; and reading 256 or 512 descriptors per round trip instead of 64 -- 4 or 8 times the
+// lines per poll -- costs 25-40 us, profiles/r06_ab_lookback_window_*.txt).
+// `longChains`: the element has more than 16 tiles -- dozens to ~1500 tiles of one element in flight, long waits:
+// the pause starts at its maximum (1 x 128 Mi encode 112.5 -> 105.8 us against the doubling pause, 16 x 8 Mi 119.9 ->
+// 113.1; on 256 x 512 Ki, 16 tiles per element, the doubling pause is the better one by 1 %: profiles/r06_ab_poll_pause_*.txt).
+__device__ __forceinline__ uint32_t lookBackExclusive(const uint64_t* desc, uint32_t tile, uint32_t lane, bool& failed, bool longChains) {
+  uint32_t exclusive = 0;
+  int base = (int)tile - 1;
+  while (base >= 0) {
+    uint32_t sum = 0;  // aggregates of this lane's descriptors down to (and including) its first inclusive one
+    bool sawIncl = false, sawFailed = false;
+    uint64_t d[kLookbackPerLane];
+#pragma unroll
+    for (int j = 0; j < (int)kLookbackPerLane; ++j) {  // all of the lane's loads in flight at once
+      const int idx = base - (int)(lane * kLookbackPerLane) - j;
+      d[j] = kDescInclusive;  // virtual tile -1: inclusive prefix 0
+      if (idx >= 0) d[j] = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int j = 0; j < (int)kLookbackPerLane; ++j) {
+      if (sawIncl) continue;  // (beyond the lane's first inclusive prefix nothing counts)
+      const int idx = base - (int)(lane * kLookbackPerLane) - j;
+      uint32_t pause = longChains ? kLookbackPollPauseMax : 1u;  // in units of s_sleep(8) = 512 cycles: 1, 2, 4, ... kLookbackPollPauseMax
+      while ((d[j] >> 62) == 0) {
+        for (uint32_t q = 0; q < pause; ++q) __builtin_amdgcn_s_sleep(8);
+        pause = pause * 2u < kLookbackPollPauseMax ? pause * 2u : kLookbackPollPauseMax;
+        d[j] = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      sum += (uint32_t)d[j];
+      sawFailed = sawFailed || (d[j] & kDescFailed) != 0ull;
+      sawIncl = (d[j] >> 62) == 2;
+    }
+    const uint64_t inclMask = __ballot(sawIncl);
+    const int firstIncl = inclMask ? (__ffsll((unsigned long long)inclMask) - 1) : 64;
+    const bool counted = (int)lane <= firstIncl;
+    exclusive += waveReduceSum(counted ? sum : 0u);
+    failed = failed || __ballot(counted && sawFailed) != 0ull;
+    if (firstIncl < 64) break;
+    base -= 64 * (int)kLookbackPerLane;
+  }
+  return exclusive;
+}
+
 // Persistent workgroups, STATIC tile map with claim words.  Workgroup w owns the
 // tickets w, w + G, w + 2G, ... (G = gridDim.x; ticket t -> element t % B, tile
 // t / B) and walks them in order: no ticket atomic on the critical path and a
@@ -738,7 +800,6 @@ __device__ __forceinline__ uint32_t encodeRows(
 // histogram that does not cover the data, see encodeRows).  The element's last tile finds the flag in its inclusive
 // prefix and reports the element as FAILED -- outSize[b] = 0, archive magic cleared -- instead of as a success with
 // a corrupt archive.  (Upstream has no such outcome: its per-block scratch is simply overrun, GpuANSEncode.cuh:355-358.)
-constexpr uint64_t kDescFailed = 1ull << 40;
 template <int P, uint32_t FT, bool kSpill, uint32_t kTB, bool kPersistent>
 __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_ans_encode(EncodeArgs a) {
   static_assert(kTB >= 2u, "single-block elements are k_ans_encode_pair's");
@@ -941,41 +1002,8 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 
-        // decoupled look-back, 64 * kLookbackPerLane predecessors per step (lane l holds the kLookbackPerLane nearest
-        // ones beyond those of lanes < l)
-        uint32_t exclusive = 0;
         bool failed = tileFailed;
-        int base = (int)tile - 1;
-        while (base >= 0) {
-          uint32_t sum = 0;       // aggregates of this lane's descriptors down to (and including) its first inclusive one
-          bool sawIncl = false, sawFailed = false;
-          uint64_t d[kLookbackPerLane];
-#pragma unroll
-          for (int j = 0; j < (int)kLookbackPerLane; ++j) {  // all of the lane's loads in flight at once
-            const int idx = base - (int)(lane * kLookbackPerLane) - j;
-            d[j] = kDescInclusive;  // virtual tile -1: inclusive prefix 0
-            if (idx >= 0) d[j] = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-#pragma unroll
-          for (int j = 0; j < (int)kLookbackPerLane; ++j) {
-            if (sawIncl) continue;  // (beyond the lane's first inclusive prefix nothing counts)
-            const int idx = base - (int)(lane * kLookbackPerLane) - j;
-            while ((d[j] >> 62) == 0) {
-              __builtin_amdgcn_s_sleep(1);
-              d[j] = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            sum += (uint32_t)d[j];
-            sawFailed = sawFailed || (d[j] & kDescFailed) != 0ull;
-            sawIncl = (d[j] >> 62) == 2;
-          }
-          const uint64_t inclMask = __ballot(sawIncl);
-          const int firstIncl = inclMask ? (__ffsll((unsigned long long)inclMask) - 1) : 64;
-          const bool counted = (int)lane <= firstIncl;
-          exclusive += waveReduceSum(counted ? sum : 0u);
-          failed = failed || __ballot(counted && sawFailed) != 0ull;
-          if (firstIncl < 64) break;
-          base -= 64 * (int)kLookbackPerLane;
-        }
+        const uint32_t exclusive = lookBackExclusive(desc, tile, lane, failed, numTiles > 16u);
 
         const uint32_t inclusive = exclusive + aggregate;
         if (lane == 0) {

@@ -79,7 +79,13 @@ def main():
     if head is None:
         print(f"# no run of exactly {W + K} steps: taking the first run of at least that length")
         head = next(r for r in runs if len(r) >= W + K)[: W + K]
-    steady = max(runs, key=len)
+    # bench.py's loops after the headline: one buffer set (W + K), then the steady-state pair -- the ROTATING loop behind
+    # its pre-roll (400 + max(K, 200) steps), then the one-buffer-set loop the same way -- with no other kernel between
+    # them: one long run.  The rotating steady state is steps [W + K + 400, W + K + 400 + max(K, 200)) of it.
+    longest = max(runs, key=len)
+    KS = max(K, 200)
+    lo = W + K + 400
+    steady = longest[lo: lo + KS] if len(longest) >= lo + KS else longest[len(longest) // 2:]
     clocks = load_clocks(clk)
     col = None
     if clocks:
@@ -124,10 +130,9 @@ def main():
         nxt = steady[i + 1][0][0] if i + 1 < len(steady) else None
         st.append({"h": (h[1] - h[0]) / 1e3, "g1": (e[0] - h[1]) / 1e3, "e": (e[1] - e[0]) / 1e3, "g2": (d[0] - e[1]) / 1e3,
                    "d": (d[1] - d[0]) / 1e3, "g3": (nxt - d[1]) / 1e3 if nxt else None, "p": (nxt - h[0]) / 1e3 if nxt else None})
-    st = st[len(st) // 2:]  # its second half: behind the pre-roll
     print()
     print("# averages per step                     hist      enc      dec   gap h>e  gap e>d  gap d>h   kernels     gaps    period")
-    for label, rs in (("timed region (%d steps)" % K, timed), ("steady state (last %d steps of the longest run)" % len(st), st)):
+    for label, rs in (("timed region (%d steps)" % K, timed), ("steady state (rotating loop behind 400 steps, %d steps)" % len(st), st)):
         kern = avg(rs, "h") + avg(rs, "e") + avg(rs, "d")
         gaps = avg(rs, "g1") + avg(rs, "g2") + avg(rs, "g3")
         print("# %-36s %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f  %8.1f %8.1f  %8.1f" % (
@@ -139,7 +144,7 @@ def main():
     if times:
         a, b = head[0][0][0], head[-1][2][1]
         inside = [r for r in clocks if a <= r[col] <= b]
-        s_lo, s_hi = steady[len(steady) // 2][0][0], steady[-1][2][1]
+        s_lo, s_hi = steady[0][0][0], steady[-1][2][1]
         inside_st = [r for r in clocks if s_lo <= r[col] <= s_hi]
         for label, rs in (("headline region", inside), ("steady-state loop", inside_st)):
             if rs:

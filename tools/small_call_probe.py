@@ -18,11 +18,16 @@ import statistics
 import sys
 import time
 
-sys.path.insert(0, ".")
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def clocks():
     return [time.clock_gettime_ns(c) for c in (time.CLOCK_MONOTONIC, time.CLOCK_BOOTTIME, time.CLOCK_REALTIME)]
+
+
+BATCH = 1  # --batch: tensors per call (the rows of one [BATCH, n] tensor)
 
 
 def setup(n, dt):
@@ -33,14 +38,15 @@ def setup(n, dt):
     ops = dietgpu_amd.load_torch_ops()
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(1234)
-    t = torch.randn([n], generator=g, device=dev, dtype=torch.float32).to(dt)
-    r, c = ops.max_float_compressed_output_size([t])
+    t = torch.randn([BATCH, n], generator=g, device=dev, dtype=torch.float32).to(dt)
+    ts = list(t.unbind(0))
+    r, c = ops.max_float_compressed_output_size(ts)
     comp = torch.empty([r, c], dtype=torch.uint8, device=dev)
-    sizes = torch.zeros([1], dtype=torch.int32, device=dev)
+    sizes = torch.zeros([BATCH], dtype=torch.int32, device=dev)
     out = torch.empty_like(t)
-    status = torch.empty([1], dtype=torch.uint8, device=dev)
-    osz = torch.empty([1], dtype=torch.int32, device=dev)
-    return ops, t, comp, sizes, out, status, osz
+    status = torch.empty([BATCH], dtype=torch.uint8, device=dev)
+    osz = torch.empty([BATCH], dtype=torch.int32, device=dev)
+    return ops, ts, comp, sizes, list(out.unbind(0)), status, osz
 
 
 def measure(a):
@@ -51,15 +57,16 @@ def measure(a):
     for m in [float(x) for x in a.sizes.split(",")]:
         n = int(m * 1024 * 1024)
         ops, t, comp, sizes, out, status, osz = setup(n, torch.bfloat16)
-        enc = lambda: ops.compress_data(True, [t], False, temp, comp, sizes)
+        enc = lambda: ops.compress_data(True, t, False, temp, comp, sizes)
         enc()
         torch.cuda.synchronize()
-        comp_ts = [comp[0, : int(sizes[0].item())]]
-        dec = lambda: ops.decompress_data(True, comp_ts, [out], False, temp, status, osz)
+        comp_ts = [comp[i, : int(s)] for i, s in enumerate(sizes.tolist())]
+        dec = lambda: ops.decompress_data(True, comp_ts, out, False, temp, status, osz)
         dec()
         torch.cuda.synchronize()
-        assert torch.equal(t.view(torch.int16), out.view(torch.int16))
-        row = {"mega_floats": m, "bytes": n * 2}
+        assert all(torch.equal(a.view(torch.int16), b.view(torch.int16)) for a, b in zip(t, out))
+        row = {"mega_floats": m, "batch": BATCH, "bytes": n * 2 * BATCH}
+        n = n * BATCH
         for name, fn in (("compress", enc), ("decompress", dec)):
             for _ in range(20):
                 fn()
@@ -98,11 +105,11 @@ def trace(a):
     for m in [float(x) for x in a.sizes.split(",")]:
         n = int(m * 1024 * 1024)
         ops, t, comp, sizes, out, status, osz = setup(n, torch.bfloat16)
-        enc = lambda: ops.compress_data(True, [t], False, temp, comp, sizes)
+        enc = lambda: ops.compress_data(True, t, False, temp, comp, sizes)
         enc()
         torch.cuda.synchronize()
-        comp_ts = [comp[0, : int(sizes[0].item())]]
-        dec = lambda: ops.decompress_data(True, comp_ts, [out], False, temp, status, osz)
+        comp_ts = [comp[i, : int(s)] for i, s in enumerate(sizes.tolist())]
+        dec = lambda: ops.decompress_data(True, comp_ts, out, False, temp, status, osz)
         for name, fn in (("compress", enc), ("decompress", dec)):
             for _ in range(10):
                 fn()
@@ -164,7 +171,9 @@ if __name__ == "__main__":
     ap.add_argument("--trace", default=None)
     ap.add_argument("--trace-reps", type=int, default=40)
     ap.add_argument("--merge", nargs=2, default=None)
+    ap.add_argument("--batch", type=int, default=1, help="tensors per call (each of --sizes Mi words)")
     a = ap.parse_args()
+    BATCH = a.batch
     if a.merge:
         merge(*a.merge)
     elif a.trace:
