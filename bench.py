@@ -208,7 +208,6 @@ def algorithmic_bytes(kernel, codec, comp_total):
             "k_float_histogram": E * wb,            # read the float words once
             "k_stats_single": E * wb,               # (batches of single-block elements: one wavefront per element)
             "k_ans_encode": E * wb + nc + ans,      # read words, write non-comp plane + rANS archive (split fused in)
-            "k_float_compress_fused": E * wb + nc + ans,  # the whole compress direction in one kernel, one read
             "k_ans_decode": ans + nc + E * wb,      # read archive + non-comp plane, write words (join fused in)
             "k_ans_encode_pair": E * wb + nc + ans,  # (single-block elements, two per wavefront: same bytes)
             "k_ans_decode_pair": ans + nc + E * wb,
@@ -880,7 +879,7 @@ def main():
         def direction(table):
             """compress = algorithmic bytes of the direction / (histogram + encode), decompress = ... / decode"""
             hist = next((v["avg_us"] for k, v in table.items() if "histogram" in k or "stats" in k), 0.0)
-            enc = sum(v["avg_us"] for k, v in table.items() if k.startswith("k_ans_encode") or k == "k_float_compress_fused")
+            enc = sum(v["avg_us"] for k, v in table.items() if k.startswith("k_ans_encode"))
             dec = sum(v["avg_us"] for k, v in table.items() if k.startswith("k_ans_decode"))
             frac = lambda us: round(dir_alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if us else None
             return {"compress": {"kernels_us": round(hist + enc, 2), "histogram_us": hist, "encode_us": enc, "frac": frac(hist + enc)},

@@ -17,13 +17,11 @@
 #include <mutex>
 #include <string>
 #include <thread>
-#include <type_traits>
 #include <vector>
 
 #include "format.h"
 #include "kernels_decode.h"
 #include "kernels_encode.h"
-#include "kernels_fused.h"
 #include "kernels_pairs.h"
 #include "kernels_stats.h"
 
@@ -149,9 +147,6 @@ struct StreamState {
   std::vector<void*> graphSlabs;
   // 65536 arrival counters + kAccElements x 256 histogram counters + 16384 spill-pool flags (zero at rest)
   uint32_t* counters = nullptr;
-  // k_float_compress_fused's hand-off words (kernels_fused.h), zero at rest: [65536] tile claims, [65536] count claims,
-  // [65536] u64 descriptors, the exit counter
-  uint32_t* fused = nullptr;
   // a call was CAPTURED into a HIP graph with pointers into this state (slab, counters): the graph replays without
   // passing through the library, so the state is never trimmed or released implicitly (dgpu_release_graph_state)
   bool graphPinned = false;
@@ -164,8 +159,6 @@ struct StreamState {
     slabInGraph = false;
     if (slab) (void)hipFree(slab);
     if (counters) (void)hipFree(counters);
-    if (fused) (void)hipFree(fused);
-    fused = nullptr;
     slab = nullptr;
     slabCap = 0;
     counters = nullptr;
@@ -242,7 +235,6 @@ class StreamRegistry {
         (void)hipGetLastError();
         s->slab = nullptr;  // cannot prove idleness: leak rather than free under running kernels
         s->counters = nullptr;
-        s->fused = nullptr;
         s->retired.clear();
         s->graphSlabs.clear();
       }
@@ -1104,94 +1096,6 @@ bool histogramLoadsNonTemporal(uint32_t ft) {
   return m < 0 ? kNtHistLoads : m == 0;
 }
 
-// ---------------------------------------------------------------------------
-// Float compress in one kernel with one read of the input (kernels_fused.h) for batches of equally sized tensors of
-// whole tiles: the T tiles of an element are in flight together (T <= the workgroups that fit on the chip) and a tile's
-// compressed bytes wait in LDS for the element's table.  DGPU_FUSED / dgpu_debug_set_fused_compress: -1 = the policy
-// below, 0 = never, 1 = whenever the batch is eligible.
-std::atomic<int> g_fusedMode{[] {
-  const char* e = getenv("DGPU_FUSED");
-  return e && *e ? atoi(e) : -1;
-}()};
-std::atomic<uint32_t> g_fusedHelpAfterPolls{4096};  // (test hook: 1 makes every waiting workgroup count for others)
-constexpr size_t kFusedMaxTickets = 65536;
-constexpr size_t kFusedMaxBatch = 2048;  // arrival words: one per element, each in a 128-byte line of its own (kFusedArriveStride)
-// u32 words: claims, count claims, 2 per descriptor, exit counter, arrival words
-constexpr size_t kFusedStateWords = kFusedMaxTickets * 4u + 64u + kFusedMaxBatch * kFusedArriveStride;
-
-template <int P, uint32_t FT>
-uint32_t fusedResidentPF() {
-  static const uint32_t perCu = [] {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (k_float_compress_fused<P, FT>), 256, fusedLdsBytes(P, FT)) != hipSuccess || n < 1) n = 1;
-    return (uint32_t)n;
-  }();
-  return perCu * numComputeUnits();
-}
-uint32_t fusedResident(int P, uint32_t ft) {
-  switch (ft) {
-    case kFloat16: return P == 9 ? fusedResidentPF<9, kFloat16>() : P == 10 ? fusedResidentPF<10, kFloat16>() : fusedResidentPF<11, kFloat16>();
-    case kBFloat16: return P == 9 ? fusedResidentPF<9, kBFloat16>() : P == 10 ? fusedResidentPF<10, kBFloat16>() : fusedResidentPF<11, kBFloat16>();
-    default: return P == 9 ? fusedResidentPF<9, kFloat32>() : P == 10 ? fusedResidentPF<10, kFloat32>() : fusedResidentPF<11, kFloat32>();
-  }
-}
-template <int P, uint32_t FT>
-void launchFusedPF(const FusedArgs& a, uint32_t grid, hipStream_t stream) {
-  DGPU_LAUNCH("k_float_compress_fused", stream, (k_float_compress_fused<P, FT>), dim3(grid), dim3(256), fusedLdsBytes(P, FT), stream, a);
-}
-template <uint32_t FT>
-void launchFusedF(int P, const FusedArgs& a, uint32_t grid, hipStream_t stream) {
-  if (P == 9) launchFusedPF<9, FT>(a, grid, stream);
-  else if (P == 10) launchFusedPF<10, FT>(a, grid, stream);
-  else launchFusedPF<11, FT>(a, grid, stream);
-}
-struct FusedPlan {
-  uint32_t tiles = 0, grid = 0;
-  bool partials = false;  // per-tile counts through temp memory (else: atomic counters)
-  uint32_t accSets = 1;   // ... in this many sets of 256 per element (an element's tiles spread over them)
-};
-// `uniformAligned`: every element has `size` words and starts at a 16-byte boundary (the caller knows)
-bool planFused(int P, uint32_t ft, uint32_t B, uint32_t size, bool uniformAligned, FusedPlan* fp) {
-  const int mode = g_fusedMode.load();
-  if (mode == 0 || !uniformAligned || ft == 0 || B == 0 || size == 0) return false;
-  constexpr uint32_t kTileWords = kBlocksPerTile * kBlockSize;
-  if (size % kTileWords != 0) return false;
-  const uint32_t T = size / kTileWords;
-  if ((uint64_t)B * T > kFusedMaxTickets || B > kFusedMaxBatch) return false;
-  const uint32_t resident = fusedResident(P, ft);
-  if (T > resident) return false;  // the tiles of an element must be in flight together
-  if (T > kFusedMaxPartials && B > kAccElements) return false;
-  fp->tiles = T;
-  fp->grid = std::min(B * T, resident);
-  fp->partials = T <= kFusedMaxPartials;
-  // 512 workgroups adding into ONE set of 256 counters queue 512 deep per address (a 16 Mi-word tensor: 58 us against
-  // 40 for the two-kernel path); spread over up to 16 sets the normalising workgroup sums one more round of loads
-  fp->accSets = 1;
-  while (!fp->partials && fp->accSets < 16u && B * fp->accSets * 2u <= kAccElements) fp->accSets *= 2u;
-  return true;
-}
-int fusedState(StreamLease& lease, uint32_t** state) {
-  hipError_t e = hipSuccess;
-  StreamState* s = lease.state(&e);
-  if (!s) return fail(DGPU_ERR_HIP, std::string("stream state: ") + hipGetErrorString(e));
-  if (!s->fused) {
-    if (lease.capturing()) {
-      return fail(DGPU_ERR_HIP, "HIP graph capture: the stream's hand-off words of the fused compress kernel do not exist yet and "
-                                "cannot be allocated while the stream is being captured: run the same call once before capturing");
-    }
-    uint32_t* p = nullptr;
-    DGPU_HIP(hipMalloc((void**)&p, kFusedStateWords * sizeof(uint32_t)));
-    hipError_t me = hipMemsetAsync(p, 0, kFusedStateWords * sizeof(uint32_t), lease.stream());
-    if (me != hipSuccess) {
-      (void)hipFree(p);
-      return fail(DGPU_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(me));
-    }
-    s->fused = p;
-  }
-  *state = s->fused;
-  return DGPU_OK;
-}
-
 // Shared tail of every encode entry point: [checksum] -> histogram (+ fused
 // normalisation) -> encode.  `in` holds raw bytes (floatType == 0: the ANS
 // archive is the whole output) or float words (floatType != 0: the encoder
@@ -1204,8 +1108,7 @@ int encodeCommon(
     const BatchView& in, const BatchView& archives, uint32_t floatType, uint32_t maxSize,
     const uint32_t* hist_dev /*may be null*/, uint32_t* outSize_dev,
     uint32_t outCapacity = 0xffffffffu /* bytes at every archive pointer; block data beyond it is dropped */,
-    const RaggedPlan* plan = nullptr, const uint32_t* work_dev = nullptr /* the plan's lists on the device */,
-    bool uniformAligned = false /* every element has maxSize symbols and starts at a 16-byte boundary */) {
+    const RaggedPlan* plan = nullptr, const uint32_t* work_dev = nullptr /* the plan's lists on the device */) {
   const uint32_t wordBytes = floatType ? floatWordBytes(floatType) : 1u;
   const uint32_t maxTiles = tilesFor(maxSize);
 
@@ -1221,76 +1124,6 @@ int encodeCommon(
     DGPU_HIP(hipGetLastError());
   }
 
-
-  // Equally sized float tensors of whole tiles: ONE kernel, one read of the input (kernels_fused.h)
-  FusedPlan fp;
-  if (floatType && !hist_dev && !(plan && plan->use) && planFused(P, floatType, B, maxSize, uniformAligned, &fp)) {
-    FusedArgs f;
-    f.in = in;
-    f.out = archives;
-    f.numInBatch = B;
-    f.tiles = fp.tiles;
-    f.size = maxSize;
-    f.numTickets = B * fp.tiles;
-    DGPU_ALLOC(ftable, uint4, arena, (size_t)B * kNumSymbols);
-    f.encTable = ftable;
-    f.histParts = nullptr;
-    f.histAcc = nullptr;
-    uint32_t *arrive = nullptr, *acc = nullptr, *state = nullptr;
-    int rc = arrivalCounters(lease, &arrive, &acc);
-    if (rc) return rc;
-    rc = fusedState(lease, &state);
-    if (rc) return rc;
-    if (fp.partials) {
-      DGPU_ALLOC(parts, uint32_t, arena, (size_t)B * fp.tiles * kNumSymbols);
-      f.histParts = parts;
-    } else {
-      f.histAcc = acc;
-    }
-    (void)arrive;
-    f.arrive = state + 4 * kFusedMaxTickets + 64;
-    f.claims = state;
-    f.countClaims = state + kFusedMaxTickets;
-    f.tileDesc = (uint64_t*)(state + 2 * kFusedMaxTickets);
-    f.exitCount = state + 4 * kFusedMaxTickets;
-    DGPU_ALLOC(fspill, uint16_t, arena, (size_t)fp.grid * kBlocksPerTile * encSpillSlotWords(P));
-    f.spill = fspill;
-    f.outSize = outSize_dev;
-    f.outCapacity = outCapacity;
-    f.useChecksum = useChecksum ? 1 : 0;
-    f.checksum = useChecksum ? checksumTemp : nullptr;
-    f.accSets = fp.accSets;
-    f.absentModulo = absentWorkgroupModulo();
-    f.helpAfterPolls = std::max(1u, g_fusedHelpAfterPolls.load());
-    NormalizeArgs& n = f.norm;
-    n.sizes = in;
-    n.hist = f.histParts;
-    n.histAcc = f.histAcc;
-    n.histParts = fp.tiles;
-    n.histAccSets = fp.accSets;
-    n.probBits = P;
-    n.encTable = ftable;
-    n.refTable = nullptr;
-    n.out = archives;
-    n.writeHeader = 1;
-    n.floatType = floatType;
-    n.useChecksum = 0;  // ANS-level checksums are not used in float mode (GpuFloatCodec.h:50)
-    n.checksum = nullptr;
-    n.outSize = outSize_dev;
-    n.floatUseChecksum = useChecksum ? 1 : 0;
-    n.tileDesc = nullptr;  // (the fused kernel's descriptors and claim words are zero at rest)
-    n.maxTiles = fp.tiles;
-    n.claims = nullptr;
-    n.numInBatch = B;
-    n.tileBase = nullptr;
-    n.tileSymbols = kBlocksPerTile * kBlockSize;
-    n.tableInKernel = 1;
-    if (floatType == kFloat16) launchFusedF<kFloat16>(P, f, fp.grid, stream);
-    else if (floatType == kBFloat16) launchFusedF<kBFloat16>(P, f, fp.grid, stream);
-    else launchFusedF<kFloat32>(P, f, fp.grid, stream);
-    DGPU_HIP(hipGetLastError());
-    return DGPU_OK;
-  }
 
   // Encoder tables [B][256] x 16 bytes, normalisation -> encoder.  Not for batches of single-block elements: there
   // the table would be as many bytes as the element's symbols, and k_ans_encode_pair derives it from the pdf table in
@@ -1338,7 +1171,6 @@ int encodeCommon(
   n.hist = hist_dev;
   n.histAcc = nullptr;
   n.histParts = 1;
-  n.histAccSets = 1;
   n.probBits = P;
   n.encTable = table;
   n.refTable = nullptr;
@@ -1356,7 +1188,6 @@ int encodeCommon(
   n.numInBatch = B;
   n.tileBase = lists ? work_dev + (size_t)plan->numTiles + plan->numHistParts : nullptr;
   n.tileSymbols = tileBlocks * kBlockSize;
-  n.tableInKernel = 0;
 
   if (!hist_dev && tileBlocks == kBlocksPerSingleTile && maxTiles > 0 && floatType != kFloat32) {
     // batches of single-block elements: one wavefront counts and normalises an element (kernels_pairs.h); no partial
@@ -1521,9 +1352,6 @@ int floatCompressImpl(
   int rc = DGPU_OK;
   RaggedPlan plan;
   const uint32_t* work_dev = nullptr;
-  // every element `maxSize` words long and 16-byte aligned: the one-kernel path is open (planFused)
-  bool uniformAligned = true;
-  for (uint32_t i = 0; i < B && uniformAligned; ++i) uniformAligned = hp.sizes[i] == maxSize && (hp.inPtrs[i] & 15u) == 0;
   if (!asStrideViews(hp, false, &in, &out)) {
     const uint64_t *inP = nullptr, *outP = nullptr;
     const uint32_t* sz = nullptr;
@@ -1541,7 +1369,7 @@ int floatCompressImpl(
 
   // No exponent plane in temp memory: the encoder splits the float words itself.
   rc = encodeCommon(arena, streamLease, stream, P, useChecksum != 0, B, in, out, ft, maxSize, nullptr, outSize_dev, 0xffffffffu, &plan,
-                    work_dev, uniformAligned);
+                    work_dev);
   if (tempUsed) *tempUsed = arena.requested();
   return rc;
 }
@@ -1790,10 +1618,6 @@ void dgpu_debug_set_encoder_dispatch(int mode) { g_encDispatch.store(mode < 0 ? 
 void dgpu_debug_set_decoder_order(int order) { g_decOrder.store(order); }
 void dgpu_debug_set_param_cache(int on) { g_paramCacheEnabled.store(on != 0); }
 void dgpu_debug_set_work_lists(int mode) { g_workLists.store(mode < 0 ? -1 : (mode ? 1 : 0)); }
-void dgpu_debug_set_fused_compress(int mode, uint32_t helpAfterPolls) {
-  g_fusedMode.store(mode < 0 ? -1 : (mode ? 1 : 0));
-  g_fusedHelpAfterPolls.store(helpAfterPolls ? helpAfterPolls : 4096u);
-}
 void dgpu_set_histogram_load_policy(int mode) { g_histLoadPolicy.store(mode < 0 ? -1 : (mode != 0)); }
 int dgpu_release_graph_state(void) {
   const int n = paramCache().releaseGraphPins();
@@ -2106,9 +1930,8 @@ int dgpu_float_compress_stride_capped(
   TempArena arena(temp_dev, tempBytes, streamLease);
   const BatchView in = viewStride(in_dev, inStrideBytes, inWords);
   const BatchView out = viewStride(out_dev, outStrideBytes, 0);
-  const bool uniformAligned = ((uintptr_t)in_dev % 16) == 0 && (numInBatch <= 1 || inStrideBytes % 16 == 0);
   int rc = encodeCommon(arena, streamLease, st, probBits, useChecksum != 0, numInBatch, in, out, floatType, inWords, nullptr,
-                        outSize_dev, outCapacityBytes, nullptr, nullptr, uniformAligned);
+                        outSize_dev, outCapacityBytes);
   if (tempUsed) *tempUsed = arena.requested();
   return rc;
 }
@@ -2284,7 +2107,6 @@ int dgpu_ans_calc_weights(
   n.hist = histogram_dev;
   n.histAcc = nullptr;
   n.histParts = 1;
-  n.histAccSets = 1;
   n.probBits = probBits;
   n.encTable = nullptr;
   n.refTable = (uint4*)table_dev;
@@ -2301,7 +2123,6 @@ int dgpu_ans_calc_weights(
   n.numInBatch = numInBatch;
   n.tileBase = nullptr;
   n.tileSymbols = 0;
-  n.tableInKernel = 0;
   hipLaunchKernelGGL(k_normalize, dim3(numInBatch), dim3(256), 0, (hipStream_t)stream, n);
   DGPU_HIP(hipGetLastError());
   return DGPU_OK;

@@ -527,9 +527,7 @@ static_assert(encGuardLimit(9, 120) + 256u <= encStageWords(9) + kEncGuardSlackW
 // `symbol index < n`.  Three VALU more per row than the full-block step, against the scalar path's one memory round
 // trip per eight rows (bf16, 256 x 530 000: encode 120 -> 112 us, 32768 x 4000: 237 -> 138 us;
 // profiles/r05_ab_partial_blocks.txt).
-// kLdsSrc (with kFull, not kTail; k_float_compress_fused): the block's 4096 symbols already lie in LDS in natural order
-// at `ring` -- nothing is loaded or split here, chunk c is the 32 * kRows bytes at ring + c * 32 * kRows.
-template <int P, uint32_t FT, bool kFull, bool kSpill, bool kGuard = false, bool kPool = false, bool kTail = false, bool kLdsSrc = false>
+template <int P, uint32_t FT, bool kFull, bool kSpill, bool kGuard = false, bool kPool = false, bool kTail = false>
 __device__ __forceinline__ uint32_t encodeRows(
     const ChunkSource<FT>& src,
     uint32_t n,                           // symbols in this half's block (0 = idle half)
@@ -546,7 +544,6 @@ __device__ __forceinline__ uint32_t encodeRows(
     SpillPool* pool = nullptr) {
   static_assert(!kPool || kSpill, "");
   static_assert(!kTail || kFull, "kTail is a mode of the chunked path");
-  static_assert(!kLdsSrc || (kFull && !kTail), "kLdsSrc is a mode of the full-block path");
   const uint32_t laneMaskLt = (1u << hl) - 1u;
   uint32_t state = kStartState;
   uint32_t outOff = 0;
@@ -639,17 +636,13 @@ __device__ __forceinline__ uint32_t encodeRows(
     constexpr uint32_t kChunkRows = ChunkSource<FT>::kRows;
     static_assert(kSymAhead > kAhead && kSymAhead <= (int)kChunkRows, "a symbol slot is reused only after its table load was issued");
     const uint32_t numChunks = kTail ? divUp(maxRows, kChunkRows) : kRowsPerBlock / kChunkRows;  // (uniform)
-    typename ChunkSource<FT>::Raw cur;
-    if constexpr (!kLdsSrc) cur = kTail ? src.loadTail(0, hl, n) : src.load(0, hl);
+    typename ChunkSource<FT>::Raw cur = kTail ? src.loadTail(0, hl, n) : src.load(0, hl);
 #pragma unroll 1
     for (uint32_t c = 0; c < numChunks; ++c) {
-      if constexpr (!kLdsSrc) {
-        if (kTail) src.consumeTail(cur, c, hl, ring, n);
-        else src.consume(cur, c, hl, ring);
-        if (c + 1 < numChunks) cur = kTail ? src.loadTail(c + 1, hl, n) : src.load(c + 1, hl);
-      }
-      const uint8_t* chunkSyms = kLdsSrc ? ring + c * (kChunkRows * 32u) : ring;
-      auto symAt = [&](int r) -> uint32_t { return (uint32_t)chunkSyms[r * 32 + hl]; };
+      if (kTail) src.consumeTail(cur, c, hl, ring, n);
+      else src.consume(cur, c, hl, ring);
+      if (c + 1 < numChunks) cur = kTail ? src.loadTail(c + 1, hl, n) : src.load(c + 1, hl);
+      auto symAt = [&](int r) -> uint32_t { return (uint32_t)ring[r * 32 + hl]; };
       auto fetchEntry = [&](uint32_t sym) -> uint4 { return ldsTableEntry(tableLds + (sym << 4)); };
       uint32_t sym[kSymAhead];
 #pragma unroll

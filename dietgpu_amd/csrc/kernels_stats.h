@@ -177,7 +177,6 @@ struct NormalizeArgs {
   uint32_t* histAcc;         // nullable: [B][256] counts accumulated by atomics (library-owned, zero at rest);
                              // used instead of `hist`, read and put back to zero here
   uint32_t histParts;
-  uint32_t histAccSets;      // sets of 256 counters per element in histAcc (1 except in k_float_compress_fused)
   int probBits;
   uint4* encTable;           // [B][256] nullable
   uint4* refTable;           // [B][256] nullable
@@ -197,9 +196,6 @@ struct NormalizeArgs {
   // that exist only, element by element; element b's begin at tileBase[b], it has ceil(size / tileSymbols) of them
   const uint32_t* tileBase;  // nullable: [numInBatch]
   uint32_t tileSymbols;
-  // k_float_compress_fused: the encoder table is read by workgroups of the SAME kernel, on any XCD -- it is stored
-  // write-through (agent-scope stores) instead of being left in the normalising workgroup's L2
-  uint32_t tableInKernel;
 };
 
 // The static part of the ANS archive header of element b (the fields ansEncodeCoalesce writes at
@@ -216,19 +212,7 @@ __device__ __forceinline__ void normWriteHeader(const NormalizeArgs& a, uint32_t
   h.checksum = (a.useChecksum && a.checksum) ? a.checksum[b] : 0u;
   h.unused0 = 0;
   h.unused1 = 0;
-  if (a.tableInKernel) {
-    // k_float_compress_fused: the element's last tile completes totalCompressedWords in the SAME kernel, possibly on
-    // another XCD -- two L2s that are not coherent with each other must not both hold that word dirty (whichever line
-    // is written back last would win).  Everything but that word, write-through.
-    uint32_t* w = (uint32_t*)ans;
-    const uint32_t v[8] = {h.magicAndVersion, h.numBlocks, h.totalUncompressedWords, 0u, h.options, h.checksum, 0u, 0u};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if (i != 3) __hip_atomic_store(w + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  } else {
-    *(AnsHeader*)ans = h;
-  }
+  *(AnsHeader*)ans = h;
   if (nb == 0) {
     if (a.outSize) a.outSize[b] = ansOffsetInArchive(a.floatType, total) + ansOverhead(0);
     if (a.floatType) {
@@ -290,20 +274,9 @@ __device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const u
       count = *direct;
     } else if (a.histAcc) {
       // counts accumulated with atomics by the histogram workgroups of this element
-      // (histAccSets > 1: the element's workgroups spread their additions over that many sets of counters)
-      uint32_t* acc = a.histAcc + (size_t)b * a.histAccSets * kNumSymbols + tid;
-      for (uint32_t k = 0; k < a.histAccSets; k += 4u) {
-        uint32_t c[4];
-#pragma unroll
-        for (uint32_t q = 0; q < 4u; ++q) {
-          c[q] = k + q < a.histAccSets ? __hip_atomic_load(acc + (size_t)(k + q) * kNumSymbols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        }
-#pragma unroll
-        for (uint32_t q = 0; q < 4u; ++q) {
-          count += c[q];
-          if (k + q < a.histAccSets) __hip_atomic_store(acc + (size_t)(k + q) * kNumSymbols, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero at rest
-        }
-      }
+      uint32_t* acc = a.histAcc + (size_t)b * kNumSymbols + tid;
+      count = __hip_atomic_load(acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(acc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero at rest
     } else {
       // sum of the per-workgroup partial histograms, up to 16 loads in flight
       const uint32_t* hp = (partials ? partials : a.hist + (size_t)b * a.histParts * kNumSymbols) + tid;
@@ -370,16 +343,7 @@ __device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const u
 
   }
 
-  if (a.encTable) {
-    const uint4 e = encTableEntry(pdf, cdf, P);
-    if (a.tableInKernel) {
-      uint64_t* dst = (uint64_t*)(a.encTable + b * kNumSymbols + tid);
-      __hip_atomic_store(dst, (uint64_t)e.x | ((uint64_t)e.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(dst + 1, (uint64_t)e.z | ((uint64_t)e.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      a.encTable[b * kNumSymbols + tid] = e;
-    }
-  }
+  if (a.encTable) a.encTable[b * kNumSymbols + tid] = encTableEntry(pdf, cdf, P);
   if (a.refTable) {
     // the reference's table (pdf, cdf, 33-bit magic, shift), :349-358
     uint32_t magic = 0, shift = 0;
@@ -527,11 +491,7 @@ __device__ __forceinline__ void histStore(uint32_t* __restrict__ hist, uint32_t 
   if (f.acc) {
     // few large elements: thousands of workgroups per element; their counts meet in
     // 256 atomic counters instead of thousands of partial histograms
-    // (spread over the element's sets of counters: hundreds of workgroups adding into ONE set queue that deep per address)
-    if (sum) {
-      __hip_atomic_fetch_add(f.acc + ((size_t)b * f.norm.histAccSets + (w.part & (f.norm.histAccSets - 1u))) * kNumSymbols + tid, sum,
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (sum) __hip_atomic_fetch_add(f.acc + (size_t)b * kNumSymbols + tid, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
     __hip_atomic_store(slot, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
   }

@@ -66,7 +66,7 @@ const char* dgpu_version(void);
 /* Bumped whenever an entry point of this header is added, removed or changes its meaning.  Code that is built
  * separately against this header (the tensor-op library of this repository, a cgo / JNI binding) compares the value it was compiled with
  * against the library it finds at run time, so that a stale build fails at load instead of inside a call. */
-#define DGPU_ABI_VERSION 7u
+#define DGPU_ABI_VERSION 6u
 uint32_t dgpu_abi_version(void);
 /* Text of the last error on the calling thread (HIP error string, failed
  * precondition).  The reference aborts through glog CHECK instead. */
@@ -344,14 +344,6 @@ void dgpu_debug_set_decoder_order(int order);
  * that exist and the kernels work through the lists.  -1 (default): that policy; 0: always the rectangles; 1: the
  * lists for every pointer-array call whose sizes differ.  Archives and outputs are byte-identical either way. */
 void dgpu_debug_set_work_lists(int mode);
-
-/* Measurement / test hook: float compress of equally sized tensors of whole 32 Ki-word tiles in ONE kernel with one
- * read of the input (k_float_compress_fused; replaces floatCompress's splitFloat + histogram + ansEncodeBatch sequence,
- * GpuFloatCompress.cuh:280-365, 430-560, for such batches).  mode -1 (default): the library decides per call; 0: always
- * the two-kernel path; 1: the one-kernel path for every eligible batch.  helpAfterPolls: after how many polls of an
- * element's ready bit a waiting workgroup starts counting tiles whose owner has not shown up (0 = the default; 1
- * exercises that path in tests).  Archives are byte-identical either way. */
-void dgpu_debug_set_fused_compress(int mode, uint32_t helpAfterPolls);
 
 /* Measurement hook: 0 makes every pointer-array call upload its parameter block
  * (no reuse of blocks already resident on the device); 1 (default) restores the
