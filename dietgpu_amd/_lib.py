@@ -55,6 +55,7 @@ _SIGS = {
     "dgpu_debug_set_decoder_order": (None, [i32]),
     "dgpu_debug_set_param_cache": (None, [i32]),
     "dgpu_debug_set_work_lists": (None, [i32]),
+    "dgpu_debug_set_size_classes": (None, [i32]),
     "dgpu_set_histogram_load_policy": (None, [i32]),
     "dgpu_release_graph_state": (i32, []),
 }

@@ -589,9 +589,24 @@ class ParamCache {
 
  private:
   static constexpr size_t kEntries = 16;
+  // (four independent lanes: a batch of tens of thousands of tensors has a parameter block of a megabyte, and one
+  // multiply-xor chain over it was most of such a call's host time)
   static uint64_t hashBlock(const uint8_t* p, size_t n) {
-    uint64_t h = 0x9e3779b97f4a7c15ull ^ n;
+    uint64_t h0 = 0x9e3779b97f4a7c15ull ^ n, h1 = 0xc2b2ae3d27d4eb4full, h2 = 0x165667b19e3779f9ull, h3 = 0x27d4eb2f165667c5ull;
     size_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+      uint64_t w[4];
+      memcpy(w, p + i, 32);
+      h0 = (h0 ^ w[0]) * 0xff51afd7ed558ccdull;
+      h1 = (h1 ^ w[1]) * 0xff51afd7ed558ccdull;
+      h2 = (h2 ^ w[2]) * 0xff51afd7ed558ccdull;
+      h3 = (h3 ^ w[3]) * 0xff51afd7ed558ccdull;
+      h0 ^= h0 >> 32;
+      h1 ^= h1 >> 32;
+      h2 ^= h2 >> 32;
+      h3 ^= h3 >> 32;
+    }
+    uint64_t h = h0 ^ (h1 * 3u) ^ (h2 * 5u) ^ (h3 * 7u);
     for (; i + 8 <= n; i += 8) {
       uint64_t w;
       memcpy(&w, p + i, 8);
@@ -1048,6 +1063,235 @@ bool planEncode(const std::vector<uint32_t>& sizes, uint32_t floatType, uint32_t
   return true;
 }
 
+// SIZE CLASSES inside one batch.  The tile geometry of a call -- pairs of single-block elements per wavefront, tiles of 2,
+// 4 or 8 blocks -- used to be chosen once, from the largest element (encTileBlocksFor(maxSize); upstream does the same:
+// one grid laid out for maxSize, GpuANSEncode.cuh:753-771).  One large tensor next to thousands of small ones then ran
+// every small element on an 8-block tile -- seven of its eight half-waves idle, where the pair kernels are 1.4-2 x faster
+// on such elements.  The host already lists the work of such a batch; it now lists it PER CLASS and launches each class
+// on the kernels of its own geometry, the classes one after the other on the caller's stream (large elements first).
+// All kernels index the batch's arrays by the element's own index, so a class is nothing but its lists: tiles and
+// histogram parts (EncodeArgs::workMap, HistFuse::workMap) or, for the single-block class, the elements to pair up.
+// A class of fewer than kMinClassElements elements joins the next larger one (a launch costs more than their idle
+// lanes), and a batch whose smaller classes together hold fewer than kMinSplitElements elements is not split at all:
+// in ONE launch its few small elements run beside the large ones' tiles (1 x 32 Mi + 255 x 2 Ki bf16: 71 us together
+// against 56 + 38 one after the other, profiles/r05_ab_work_lists.txt).
+constexpr uint32_t kMinClassElements = 32, kMinSplitElements = 256;
+struct EncodeClass {
+  uint32_t tileBlocks = 0;
+  uint32_t maxSize = 0;                                       // of the class's elements
+  uint32_t tilesAt = 0, numTiles = 0;                         // tiles of >= 2 blocks: [numTiles] element << 16 | tile, element by element
+  uint32_t histAt = 0, numHistParts = 0, histPartBytes = 0;   // ... [numHistParts] element << 16 | part
+  uint32_t tileBaseAt = 0;                                    // ... [B] first ticket of each of the class's elements
+  uint32_t elemsAt = 0, numElems = 0;                         // single-block class: [numElems] the elements
+};
+std::atomic<int> g_sizeClasses{[] {
+  const char* e = getenv("DGPU_SIZE_CLASSES");
+  return e && *e ? atoi(e) : -1;
+}()};
+// Splits the batch into size classes (false: one geometry for the call, as before).  `classOf(size)` -> blocks per tile /
+// workgroup of an element of that size; `pairsOk`: the single-block class has kernels of its own (not float32 encode).
+template <typename ClassOf>
+bool classifyBySize(const std::vector<uint32_t>& sizes, ClassOf classOf, bool pairsOk, uint32_t largestClass,
+                    std::vector<uint32_t>* classOfElem, std::vector<uint32_t>* classesOut) {
+  const int mode = g_sizeClasses.load();
+  const size_t B = sizes.size();
+  if (mode == 0 || g_workLists.load() == 0 || B < 2 || B > 65535u) return false;
+  std::map<uint32_t, uint32_t> count;
+  classOfElem->resize(B);
+  for (size_t b = 0; b < B; ++b) {
+    uint32_t c = classOf(sizes[b]);
+    if (c == 1u && !pairsOk) c = 2u;
+    (*classOfElem)[b] = c;
+    count[c]++;
+  }
+  if (count.size() < 2) return false;
+  // small classes join the next larger one that exists
+  for (auto it = count.begin(); it != count.end();) {
+    auto next = std::next(it);
+    if (next != count.end() && it->second < (mode == 1 ? 1u : kMinClassElements)) {
+      for (size_t b = 0; b < B; ++b) {
+        if ((*classOfElem)[b] == it->first) (*classOfElem)[b] = next->first;
+      }
+      next->second += it->second;
+      it = count.erase(it);
+    } else {
+      it = next;
+    }
+  }
+  if (count.size() < 2) return false;
+  uint32_t small = 0;
+  for (auto& kv : count) {
+    if (kv.first != count.rbegin()->first) small += kv.second;
+  }
+  if (mode != 1 && small < kMinSplitElements) return false;
+  (void)largestClass;
+  classesOut->clear();
+  for (auto it = count.rbegin(); it != count.rend(); ++it) classesOut->push_back(it->first);  // large elements first
+  return true;
+}
+bool planEncodeClasses(const std::vector<uint32_t>& sizes, uint32_t floatType, std::vector<EncodeClass>* classes, std::vector<uint32_t>* work) {
+  std::vector<uint32_t> classOfElem, order;
+  if (!classifyBySize(sizes, [](uint32_t sz) { return encTileBlocksFor(sz); }, floatType != kFloat32, kBlocksPerTile, &classOfElem, &order)) return false;
+  const size_t B = sizes.size();
+  const uint32_t wordBytes = floatType ? floatWordBytes(floatType) : 1u;
+  uint64_t totalBytes = 0;
+  for (uint32_t sz : sizes) totalBytes += (uint64_t)sz * wordBytes;
+  classes->clear();
+  for (uint32_t c : order) {
+    EncodeClass k;
+    k.tileBlocks = c;
+    std::vector<uint32_t> elems;
+    for (size_t b = 0; b < B; ++b) {
+      if (classOfElem[b] == c) {
+        elems.push_back((uint32_t)b);
+        k.maxSize = std::max(k.maxSize, sizes[b]);
+      }
+    }
+    if (c == kBlocksPerSingleTile) {
+      k.elemsAt = (uint32_t)work->size();
+      k.numElems = (uint32_t)elems.size();
+      work->insert(work->end(), elems.begin(), elems.end());
+    } else {
+      // tiles element by element, the class's larger elements first; histogram parts sized for the usual number of
+      // workgroups over the WHOLE batch (the classes run one after the other, each should fill the chip)
+      std::stable_sort(elems.begin(), elems.end(), [&](uint32_t x, uint32_t y) { return sizes[x] > sizes[y]; });
+      const uint32_t tileSymbols = c * kBlockSize;
+      std::vector<uint32_t> tileBase(B, 0u);
+      k.tilesAt = (uint32_t)work->size();
+      uint64_t classBytes = 0;
+      for (uint32_t b : elems) {
+        tileBase[b] = (uint32_t)(work->size() - k.tilesAt);
+        const uint32_t tiles = divUp(sizes[b], tileSymbols);
+        if (tiles > 65536u) {
+          work->clear();
+          classes->clear();
+          return false;
+        }
+        for (uint32_t r = 0; r < tiles; ++r) work->push_back((b << 16) | r);
+        classBytes += (uint64_t)sizes[b] * wordBytes;
+      }
+      k.numTiles = (uint32_t)(work->size() - k.tilesAt);
+      const uint64_t target = floatType == 0 ? kHistTargetWgsForListsRaw : kHistTargetWgsForLists;
+      const uint64_t partBytes = std::max<uint64_t>(32u * 1024u, roundUp64(divUp64(classBytes, target), 16u * 1024u));
+      k.histPartBytes = (uint32_t)std::min<uint64_t>(partBytes, 0x40000000ull);
+      k.histAt = (uint32_t)work->size();
+      for (uint32_t b : elems) {
+        const uint32_t parts = (uint32_t)std::max<uint64_t>(1u, divUp64((uint64_t)sizes[b] * wordBytes, k.histPartBytes));
+        if (parts > 65536u) {
+          work->clear();
+          classes->clear();
+          return false;
+        }
+        for (uint32_t q = 0; q < parts; ++q) work->push_back((b << 16) | q);
+      }
+      k.numHistParts = (uint32_t)(work->size() - k.histAt);
+      k.tileBaseAt = (uint32_t)work->size();
+      work->insert(work->end(), tileBase.begin(), tileBase.end());
+    }
+    classes->push_back(k);
+  }
+  (void)totalBytes;
+  return true;
+}
+
+// ... and the decoder's classes, from the output capacities (its tiles do not depend on one another: tile-major lists)
+struct DecodeClass {
+  uint32_t tileBlocks = 0, maxBlocks = 0;
+  uint32_t tilesAt = 0, numTiles = 0;   // tiles of >= 2 blocks: [numTiles] element << 16 | tile
+  uint32_t elemsAt = 0, numElems = 0;   // single-block class: [numElems] the elements
+};
+uint32_t decTileBlocksFor(uint32_t maxBlocks);
+bool planDecodeClasses(const std::vector<uint32_t>& caps, std::vector<DecodeClass>* classes, std::vector<uint32_t>* work) {
+  std::vector<uint32_t> classOfElem, order;
+  if (!classifyBySize(caps, [](uint32_t cap) { return decTileBlocksFor(divUp(cap, kBlockSize)); }, true, 16u, &classOfElem, &order)) return false;
+  const size_t B = caps.size();
+  classes->clear();
+  for (uint32_t c : order) {
+    DecodeClass k;
+    k.tileBlocks = c;
+    std::vector<uint32_t> elems;
+    for (size_t b = 0; b < B; ++b) {
+      if (classOfElem[b] == c) {
+        elems.push_back((uint32_t)b);
+        k.maxBlocks = std::max(k.maxBlocks, divUp(caps[b], kBlockSize));
+      }
+    }
+    if (c == 1u) {
+      k.elemsAt = (uint32_t)work->size();
+      k.numElems = (uint32_t)elems.size();
+      work->insert(work->end(), elems.begin(), elems.end());
+    } else {
+      std::stable_sort(elems.begin(), elems.end(), [&](uint32_t x, uint32_t y) { return caps[x] > caps[y]; });
+      const uint32_t tileSymbols = c * kBlockSize;
+      const uint32_t maxTiles = std::max(1u, divUp(k.maxBlocks, c));
+      if (maxTiles > 65536u) {
+        work->clear();
+        classes->clear();
+        return false;
+      }
+      k.tilesAt = (uint32_t)work->size();
+      for (uint32_t r = 0; r < maxTiles; ++r) {
+        for (uint32_t b : elems) {
+          if (std::max(divUp(caps[b], tileSymbols), 1u) <= r) break;  // (descending capacities)
+          work->push_back((b << 16) | r);
+        }
+      }
+      k.numTiles = (uint32_t)(work->size() - k.tilesAt);
+    }
+    classes->push_back(k);
+  }
+  return true;
+}
+
+// A training or collective loop compresses the same list of tensors step after step: the last plan of each kind is kept
+// per host thread and reused when the sizes (and everything else the plan depends on) are the same -- planning a batch
+// of 32 769 tensors costs ~100 us of host time, comparing its sizes 10.
+template <typename Class>
+struct ClassPlanCache {
+  std::vector<uint32_t> sizes, work;
+  std::vector<Class> classes;
+  uint32_t floatType = 0xffffffffu;
+  int modeClasses = -2, modeLists = -2;
+  bool valid = false, split = false;
+  bool matches(const std::vector<uint32_t>& sz, uint32_t ft) const {
+    return valid && floatType == ft && modeClasses == g_sizeClasses.load() && modeLists == g_workLists.load() && sizes.size() == sz.size() &&
+        (sz.empty() || memcmp(sizes.data(), sz.data(), sz.size() * 4u) == 0);
+  }
+  void remember(const std::vector<uint32_t>& sz, uint32_t ft, bool didSplit, const std::vector<Class>& cl, const std::vector<uint32_t>& wk) {
+    sizes = sz, floatType = ft, split = didSplit, classes = cl, work = wk;
+    modeClasses = g_sizeClasses.load(), modeLists = g_workLists.load();
+    valid = true;
+  }
+};
+bool planEncodeClassesCached(const std::vector<uint32_t>& sizes, uint32_t floatType, std::vector<EncodeClass>* classes, std::vector<uint32_t>* work) {
+  if (sizes.size() < kMinSplitElements) return planEncodeClasses(sizes, floatType, classes, work);  // (cheap to plan, and rarely split)
+  static thread_local ClassPlanCache<EncodeClass> cache;
+  if (!cache.matches(sizes, floatType)) {
+    std::vector<EncodeClass> cl;
+    std::vector<uint32_t> wk;
+    const bool split = planEncodeClasses(sizes, floatType, &cl, &wk);
+    cache.remember(sizes, floatType, split, cl, wk);
+  }
+  if (!cache.split) return false;
+  *classes = cache.classes;
+  *work = cache.work;
+  return true;
+}
+bool planDecodeClassesCached(const std::vector<uint32_t>& caps, std::vector<DecodeClass>* classes, std::vector<uint32_t>* work) {
+  if (caps.size() < kMinSplitElements) return planDecodeClasses(caps, classes, work);
+  static thread_local ClassPlanCache<DecodeClass> cache;
+  if (!cache.matches(caps, 0u)) {
+    std::vector<DecodeClass> cl;
+    std::vector<uint32_t> wk;
+    const bool split = planDecodeClasses(caps, &cl, &wk);
+    cache.remember(caps, 0u, split, cl, wk);
+  }
+  if (!cache.split) return false;
+  *classes = cache.classes;
+  *work = cache.work;
+  return true;
+}
+
 bool histAccumulates(uint32_t B, uint32_t maxBytes, bool raw) {
   return B <= kHistAccMaxBatch && histPartsAccFor(B, maxBytes) > histPartsFor(B, maxBytes, raw);
 }
@@ -1103,19 +1347,27 @@ bool histogramLoadsNonTemporal(uint32_t ft) {
 // on the common path: histogram workgroups store partial histograms, the last
 // one of each element sums and normalises them and clears the tile descriptors +
 // ticket for the encode kernel.
+struct EncodeShared {
+  uint32_t* checksumTemp = nullptr;  // [B] the batch's checksums (computed by the first class's call)
+  uint4* table = nullptr;            // [B][256] encoder tables, indexed by the element's own index
+};
 int encodeCommon(
     TempArena& arena, StreamLease& lease, hipStream_t stream, int P, bool useChecksum, uint32_t B,
     const BatchView& in, const BatchView& archives, uint32_t floatType, uint32_t maxSize,
     const uint32_t* hist_dev /*may be null*/, uint32_t* outSize_dev,
     uint32_t outCapacity = 0xffffffffu /* bytes at every archive pointer; block data beyond it is dropped */,
-    const RaggedPlan* plan = nullptr, const uint32_t* work_dev = nullptr /* the plan's lists on the device */) {
+    const RaggedPlan* plan = nullptr, const uint32_t* work_dev = nullptr /* the plan's lists on the device */,
+    const EncodeClass* cls = nullptr /* one size class of the batch (its lists in work_dev); maxSize is the class's */,
+    EncodeShared* shared = nullptr /* what the classes of one call share */) {
   const uint32_t wordBytes = floatType ? floatWordBytes(floatType) : 1u;
-  const uint32_t maxTiles = tilesFor(maxSize);
+  const uint32_t tileBlocks = cls ? cls->tileBlocks : encTileBlocksFor(maxSize);
+  const uint32_t maxTiles = cls ? std::max(1u, divUp(divUp(maxSize, kBlockSize), tileBlocks)) : tilesFor(maxSize);
 
-  uint32_t* checksumTemp = nullptr;
-  if (useChecksum) {
+  uint32_t* checksumTemp = shared ? shared->checksumTemp : nullptr;
+  if (useChecksum && !checksumTemp) {
     DGPU_ALLOC(ck, uint32_t, arena, B);
     checksumTemp = ck;
+    if (shared) shared->checksumTemp = ck;
     DGPU_HIP(hipMemsetAsync(checksumTemp, 0, (size_t)B * 4, stream));
     // Float quirk kept from the reference (GpuFloatCompress.cuh:466-468): the
     // size in float WORDS is consumed as a BYTE count by the checksum.
@@ -1128,23 +1380,33 @@ int encodeCommon(
   // Encoder tables [B][256] x 16 bytes, normalisation -> encoder.  Not for batches of single-block elements: there
   // the table would be as many bytes as the element's symbols, and k_ans_encode_pair derives it from the pdf table in
   // the archive header instead.
-  const uint32_t tileBlocks = encTileBlocksFor(maxSize);
-  uint4* table = nullptr;
-  if (tileBlocks != kBlocksPerSingleTile) {
+  uint4* table = shared ? shared->table : nullptr;
+  if (tileBlocks != kBlocksPerSingleTile && !table) {
     DGPU_ALLOC(tb, uint4, arena, (size_t)B * kNumSymbols);
     table = tb;
+    if (shared) shared->table = tb;
   }
-  // (work lists: descriptors and claim words for the tiles that exist only)
-  const bool lists = plan && plan->use && work_dev;
-  DGPU_ALLOC(tileDesc, uint64_t, arena, lists ? std::max<size_t>(plan->numTiles, 1u) : (size_t)B * std::max(maxTiles, 1u));
-  DGPU_ALLOC(claims, uint32_t, arena, lists ? std::max<size_t>(plan->numTiles, 1u) : (size_t)B * std::max(maxTiles, 1u));
+  // Work lists (descriptors and claim words for the tiles that exist only): a batch whose elements differ widely in
+  // size (plan), or one size class of a batch (cls)
+  const bool lists = cls ? tileBlocks != kBlocksPerSingleTile : (plan && plan->use && work_dev);
+  const uint32_t numListedTiles = !lists ? 0u : (cls ? cls->numTiles : plan->numTiles);
+  const uint32_t numListedHistParts = !lists ? 0u : (cls ? cls->numHistParts : plan->numHistParts);
+  const uint32_t listedHistPartBytes = !lists ? 0u : (cls ? cls->histPartBytes : plan->histPartBytes);
+  const uint32_t* tilesList = !lists ? nullptr : (cls ? work_dev + cls->tilesAt : work_dev);
+  const uint32_t* histList_ = !lists ? nullptr : (cls ? work_dev + cls->histAt : work_dev + (size_t)plan->numTiles);
+  const uint32_t* tileBaseList = !lists ? nullptr : (cls ? work_dev + cls->tileBaseAt : work_dev + (size_t)plan->numTiles + plan->numHistParts);
+  // (the single-block class of a batch: the elements to pair up)
+  const uint32_t* elemMap = (cls && tileBlocks == kBlocksPerSingleTile) ? work_dev + cls->elemsAt : nullptr;
+  const uint32_t numElems = elemMap ? cls->numElems : B;
+  DGPU_ALLOC(tileDesc, uint64_t, arena, lists ? std::max<size_t>(numListedTiles, 1u) : (size_t)B * std::max(maxTiles, 1u));
+  DGPU_ALLOC(claims, uint32_t, arena, lists ? std::max<size_t>(numListedTiles, 1u) : (size_t)B * std::max(maxTiles, 1u));
 
   // The encoder's grid.  `resident` = the workgroups of the kernel that fit on the chip at once.  8-block float tiles
   // run as `resident` persistent workgroups that walk the tickets with a static map; raw bytes and float tiles of 2 / 4
   // blocks run one workgroup per tile when there are more tiles than that, dispatched by the hardware in ticket order
   // (encoderHardwareDispatch); k_ans_encode_pair always runs one workgroup per pair.  Spill slots (float inputs):
   // [resident][slots per workgroup] -- a persistent workgroup's own, or a pool handed out through spillFlags.
-  const uint32_t numTickets = lists ? plan->numTiles : B * maxTiles;
+  const uint32_t numTickets = lists ? numListedTiles : (elemMap ? numElems : B * maxTiles);
   const uint32_t resident = maxTiles > 0 ? encodeGrid(P, floatType, tileBlocks, numTickets) : 0u;
   const bool hwDispatch = tileBlocks != kBlocksPerSingleTile && encoderHardwareDispatch(numTickets, resident, floatType, tileBlocks);
   uint16_t* spill = nullptr;
@@ -1186,7 +1448,7 @@ int encodeCommon(
   n.maxTiles = maxTiles;
   n.claims = claims;
   n.numInBatch = B;
-  n.tileBase = lists ? work_dev + (size_t)plan->numTiles + plan->numHistParts : nullptr;
+  n.tileBase = tileBaseList;
   n.tileSymbols = tileBlocks * kBlockSize;
 
   if (!hist_dev && tileBlocks == kBlocksPerSingleTile && maxTiles > 0 && floatType != kFloat32) {
@@ -1194,12 +1456,12 @@ int encodeCommon(
     // histograms, no arrival counters.  (Measured on 32768 elements, profiles/r04_ab_single_block_elements.txt:
     // bf16 75.5 -> 65.5 us, fp16 80.5 -> 73.7; float32 -- 16 bytes of input per symbol and lane -- 69 -> 75.5, so
     // float32 keeps the workgroup per element.)
-    const dim3 grid(divUp(B, kSingleStatWaves)), block(64u * kSingleStatWaves);
+    const dim3 grid(divUp(numElems, kSingleStatWaves)), block(64u * kSingleStatWaves);
 #define DGPU_STATS_SINGLE(FT)                                                                                           \
     if (histogramLoadsNonTemporal(floatType)) {                                                                         \
-      DGPU_LAUNCH("k_stats_single", stream, (k_stats_single<FT, true>), grid, block, 0, stream, in, n);                 \
+      DGPU_LAUNCH("k_stats_single", stream, (k_stats_single<FT, true>), grid, block, 0, stream, in, n, elemMap, numElems); \
     } else {                                                                                                            \
-      DGPU_LAUNCH("k_stats_single", stream, (k_stats_single<FT, false>), grid, block, 0, stream, in, n);                \
+      DGPU_LAUNCH("k_stats_single", stream, (k_stats_single<FT, false>), grid, block, 0, stream, in, n, elemMap, numElems); \
     }
     switch (floatType) {
       case 0: DGPU_STATS_SINGLE(0u) break;
@@ -1209,18 +1471,18 @@ int encodeCommon(
 #undef DGPU_STATS_SINGLE
     DGPU_HIP(hipGetLastError());
   } else if (!hist_dev) {
-    const bool histList = lists && plan->numHistParts != 0;
+    const bool histList = lists && numListedHistParts != 0;
     const bool accumulate = !histList && histAccumulates(B, maxSize * wordBytes, floatType == 0);
     dim3 grid(accumulate ? histPartsAccFor(B, maxSize * wordBytes) : histPartsFor(B, maxSize * wordBytes, floatType == 0), B);
-    if (histList) grid = dim3(plan->numHistParts);  // one workgroup per listed (element, part)
+    if (histList) grid = dim3(numListedHistParts);  // one workgroup per listed (element, part)
     uint32_t* histTemp = nullptr;
     if (!accumulate) {
       DGPU_ALLOC(ht, uint32_t, arena, (size_t)(histList ? 1u : B) * grid.x * kNumSymbols);
       histTemp = ht;
     }
     HistFuse fuse;
-    fuse.workMap = histList ? work_dev + (size_t)plan->numTiles : nullptr;
-    fuse.partBytes = histList ? plan->histPartBytes : 0u;
+    fuse.workMap = histList ? histList_ : nullptr;
+    fuse.partBytes = histList ? listedHistPartBytes : 0u;
     uint32_t* acc = nullptr;
     int rc = arrivalCounters(lease, &fuse.arrive, &acc);
     if (rc) return rc;
@@ -1230,7 +1492,7 @@ int encodeCommon(
     n.histParts = histList ? 1u : grid.x;
     fuse.norm = n;
     // bins with 32 lane slots unless a workgroup sees too little data to pay for zeroing / folding them
-    const bool smallBins = histList ? plan->histPartBytes <= 64u * 1024u : (uint64_t)maxSize * wordBytes / grid.x <= 64u * 1024u;
+    const bool smallBins = histList ? listedHistPartBytes <= 64u * 1024u : (uint64_t)maxSize * wordBytes / grid.x <= 64u * 1024u;
 #define DGPU_HIST_LAUNCH_NT(S, NT)                                                                                \
     switch (floatType) {                                                                                          \
       case 0:                                                                                                     \
@@ -1275,7 +1537,7 @@ int encodeCommon(
     e.maxTiles = maxTiles;
     e.numInBatch = B;
     e.numTickets = numTickets;
-    e.workMap = lists ? work_dev : nullptr;
+    e.workMap = lists ? tilesList : elemMap;
     e.tileDesc = tileDesc;
     e.claims = claims;
     e.absentModulo = absentWorkgroupModulo();
@@ -1308,6 +1570,7 @@ int ansEncodeImpl(
   ParamLease lease;
   BatchView in, out;
   RaggedPlan plan;
+  std::vector<EncodeClass> classes;
   const uint32_t* work_dev = nullptr;
   if (hp && asStrideViews(*hp, false, &in, &out)) {
     // (nothing to upload)
@@ -1316,7 +1579,8 @@ int ansEncodeImpl(
     const uint32_t* sz = nullptr;
     HostParams listed;
     const HostParams* up = hp;
-    if (planEncode(hp->sizes, 0u, maxSize, histogram_dev == nullptr, &plan, &listed.work)) {
+    if ((histogram_dev == nullptr && planEncodeClassesCached(hp->sizes, 0u, &classes, &listed.work)) ||
+        planEncode(hp->sizes, 0u, maxSize, histogram_dev == nullptr, &plan, &listed.work)) {
       listed.inPtrs = hp->inPtrs, listed.outPtrs = hp->outPtrs, listed.sizes = hp->sizes;
       up = &listed;
     }
@@ -1327,6 +1591,17 @@ int ansEncodeImpl(
   } else {
     in = *strideIn;
     out = *strideOut;
+  }
+  if (!classes.empty()) {
+    EncodeShared shared;
+    int rc = DGPU_OK;
+    for (const EncodeClass& c : classes) {
+      rc = encodeCommon(arena, streamLease, stream, P, useChecksum != 0, B, in, out, 0, c.maxSize, nullptr, outSize_dev, 0xffffffffu, nullptr,
+                        work_dev, &c, &shared);
+      if (rc) break;
+    }
+    if (tempUsed) *tempUsed = arena.requested();
+    return rc;
   }
   int rc = encodeCommon(arena, streamLease, stream, P, useChecksum != 0, B, in, out, 0, maxSize, histogram_dev, outSize_dev, 0xffffffffu,
                         &plan, work_dev);
@@ -1352,12 +1627,13 @@ int floatCompressImpl(
   int rc = DGPU_OK;
   RaggedPlan plan;
   const uint32_t* work_dev = nullptr;
+  std::vector<EncodeClass> classes;
   if (!asStrideViews(hp, false, &in, &out)) {
     const uint64_t *inP = nullptr, *outP = nullptr;
     const uint32_t* sz = nullptr;
     HostParams listed;
     const HostParams* up = &hp;
-    if (planEncode(hp.sizes, ft, maxSize, true, &plan, &listed.work)) {
+    if (planEncodeClassesCached(hp.sizes, ft, &classes, &listed.work) || planEncode(hp.sizes, ft, maxSize, true, &plan, &listed.work)) {
       listed.inPtrs = hp.inPtrs, listed.outPtrs = hp.outPtrs, listed.sizes = hp.sizes;
       up = &listed;
     }
@@ -1368,6 +1644,17 @@ int floatCompressImpl(
   }
 
   // No exponent plane in temp memory: the encoder splits the float words itself.
+  if (!classes.empty()) {
+    // every size class on the kernels of its own geometry, one after the other (EncodeClass)
+    EncodeShared shared;
+    for (const EncodeClass& c : classes) {
+      rc = encodeCommon(arena, streamLease, stream, P, useChecksum != 0, B, in, out, ft, c.maxSize, nullptr, outSize_dev, 0xffffffffu, nullptr,
+                        work_dev, &c, &shared);
+      if (rc) break;
+    }
+    if (tempUsed) *tempUsed = arena.requested();
+    return rc;
+  }
   rc = encodeCommon(arena, streamLease, stream, P, useChecksum != 0, B, in, out, ft, maxSize, nullptr, outSize_dev, 0xffffffffu, &plan,
                     work_dev);
   if (tempUsed) *tempUsed = arena.requested();
@@ -1403,7 +1690,8 @@ template <int P, uint32_t FT>
 int launchDecodePF(const DecodeArgs& a, uint32_t tileBlocks, dim3 grid, hipStream_t stream) {
   if (tileBlocks == kDecBlocksPerSingleTile) {
     // every capacity <= 4096 symbols: two elements per wavefront (kernels_pairs.h)
-    DGPU_LAUNCH("k_ans_decode_pair", stream, (k_ans_decode_pair<P, FT>), dim3((a.numInBatch + 1u) / 2u), dim3(64), decPairLdsBytes(P, FT),
+    const uint32_t elems = (a.order == kDecOrderMap && a.workMap) ? a.numListed : a.numInBatch;  // (a size class: its elements)
+    DGPU_LAUNCH("k_ans_decode_pair", stream, (k_ans_decode_pair<P, FT>), dim3((elems + 1u) / 2u), dim3(64), decPairLdsBytes(P, FT),
                 stream, a);
   } else if (tileBlocks == kDecBlocksPerTinyTile) {
     DGPU_LAUNCH("k_ans_decode", stream, (k_ans_decode<P, FT, kDecBlocksPerTinyTile>), grid, dim3(kDecBlocksPerTinyTile * 32u),
@@ -1454,6 +1742,7 @@ int decodeImpl(
   const uint32_t* inBytes_dev = nullptr;
   const uint32_t* work_dev = nullptr;
   uint32_t numListedTiles = 0;
+  std::vector<DecodeClass> classes;
   if (hp && asStrideViews(*hp, true, &in, &out)) {
     // (nothing to upload)
   } else if (hp) {
@@ -1462,7 +1751,10 @@ int decodeImpl(
     // (capacities that differ widely: only the tiles inside each element's capacity are launched, see RaggedPlan)
     HostParams listed;
     const HostParams* up = hp;
-    {
+    if (planDecodeClassesCached(hp->sizes, &classes, &listed.work)) {
+      listed.inPtrs = hp->inPtrs, listed.outPtrs = hp->outPtrs, listed.sizes = hp->sizes, listed.inBytes = hp->inBytes;
+      up = &listed;
+    } else {
       const uint32_t blocks = divUp(maxCapacity, kBlockSize);
       const uint32_t tb = decTileBlocksFor(blocks);
       if (tb != kDecBlocksPerSingleTile && planTileList(hp->sizes, tb * kBlockSize, std::max(1u, divUp(blocks, tb)), 1u, &listed.work)) {
@@ -1496,7 +1788,30 @@ int decodeImpl(
   const uint32_t maxBlocks = divUp(maxCapacity, kBlockSize);
   const uint32_t tileBlocks = decTileBlocksFor(maxBlocks);
   const uint32_t maxTiles = std::max(1u, divUp(maxBlocks, tileBlocks));
-  {
+  // every size class of the batch on the decoder of its own geometry, one after the other (DecodeClass)
+  for (const DecodeClass& c : classes) {
+    DecodeArgs d;
+    d.in = in;
+    d.out = out;
+    d.floatType = ft;
+    d.outSuccess = useChecksum ? successForChecksum : outSuccess_dev;
+    d.outSize = useChecksum ? sizesForChecksum : outSize_dev;
+    d.inBytes = inBytes_dev;
+    d.uniformInBytes = uniformInBytes;
+    d.numInBatch = B;
+    d.maxTiles = std::max(1u, divUp(c.maxBlocks, c.tileBlocks));
+    d.order = kDecOrderMap;
+    d.workMap = work_dev + (c.tileBlocks == 1u ? c.elemsAt : c.tilesAt);
+    d.numListed = c.numElems;
+    const dim3 grid(std::max(c.numTiles, 1u));
+    int rc;
+    if (ft == 0) rc = launchDecodeF<0>(P, d, c.tileBlocks, grid, stream);
+    else if (ft == kFloat16) rc = launchDecodeF<kFloat16>(P, d, c.tileBlocks, grid, stream);
+    else if (ft == kBFloat16) rc = launchDecodeF<kBFloat16>(P, d, c.tileBlocks, grid, stream);
+    else rc = launchDecodeF<kFloat32>(P, d, c.tileBlocks, grid, stream);
+    if (rc) return rc;
+  }
+  if (classes.empty()) {
     DecodeArgs d;
     d.in = in;
     d.out = out;
@@ -1509,6 +1824,7 @@ int decodeImpl(
     d.maxTiles = maxTiles;
     d.order = decodeOrder(B);
     d.workMap = nullptr;
+    d.numListed = 0;
     dim3 grid((d.order == kDecOrderXcd ? roundUp(B, 8u) : B) * maxTiles);
     if (work_dev && numListedTiles) {
       d.order = kDecOrderMap;
@@ -1618,6 +1934,7 @@ void dgpu_debug_set_encoder_dispatch(int mode) { g_encDispatch.store(mode < 0 ? 
 void dgpu_debug_set_decoder_order(int order) { g_decOrder.store(order); }
 void dgpu_debug_set_param_cache(int on) { g_paramCacheEnabled.store(on != 0); }
 void dgpu_debug_set_work_lists(int mode) { g_workLists.store(mode < 0 ? -1 : (mode ? 1 : 0)); }
+void dgpu_debug_set_size_classes(int mode) { g_sizeClasses.store(mode < 0 ? -1 : (mode ? 1 : 0)); }
 void dgpu_set_histogram_load_policy(int mode) { g_histLoadPolicy.store(mode < 0 ? -1 : (mode != 0)); }
 int dgpu_release_graph_state(void) {
   const int n = paramCache().releaseGraphPins();

@@ -58,7 +58,9 @@ struct DecodeArgs {
   uint32_t maxTiles;       // k_ans_decode: tiles per element the 1-D grid is laid out for
   uint32_t order;          // k_ans_decode: how workgroup index -> (element, tile), see decodeTileOf
   uint32_t uniformInBytes; // != 0 (and inBytes == nullptr): every archive has this many bytes available (stride batches)
-  const uint32_t* workMap; // kDecOrderMap: [grid] element << 16 | tile, the tiles that exist (the host knows the capacities)
+  const uint32_t* workMap; // kDecOrderMap: [grid] element << 16 | tile, the tiles that exist (the host knows the capacities);
+                           // k_ans_decode_pair: [numListed] the elements to pair up
+  uint32_t numListed;      // k_ans_decode_pair with a workMap: its entries
 };
 __device__ __forceinline__ uint64_t decodeInBytes(const DecodeArgs& a, uint32_t b) {
   return a.inBytes ? (uint64_t)a.inBytes[b] : (a.uniformInBytes ? (uint64_t)a.uniformInBytes : ~0ull);

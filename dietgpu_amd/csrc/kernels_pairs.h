@@ -57,14 +57,17 @@ constexpr uint32_t kSingleStatWaves = 4;  // elements (= wavefronts) per workgro
 __host__ __device__ constexpr uint32_t statSingleLdsBytes() { return kSingleStatWaves * kNumSymbols * kSingleStatSlots * 4u; }
 
 template <uint32_t FT, bool kNt>
-__global__ __launch_bounds__(64 * kSingleStatWaves) void k_stats_single(BatchView in, NormalizeArgs a) {
+// `elemMap` (nullable): the elements to work on, when they are a subset of the batch -- the single-block elements of a batch
+// that also holds larger ones, which the host sends to the kernels of their own size class (capi.hip, EncodeClass).
+__global__ __launch_bounds__(64 * kSingleStatWaves) void k_stats_single(BatchView in, NormalizeArgs a, const uint32_t* elemMap, uint32_t numElems) {
   static_assert(FT == 0 || FT == kFloat16 || FT == kBFloat16, "float32 batches keep the workgroup per element (capi.hip, encodeCommon)");
   constexpr uint32_t S = kSingleStatSlots;
   __shared__ __attribute__((aligned(16))) uint32_t sBins[kSingleStatWaves * kNumSymbols * S];
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
-  const uint32_t b = blockIdx.x * kSingleStatWaves + wave;
-  if (b >= a.numInBatch) return;  // wave-uniform; no barriers in this kernel
+  const uint32_t slot = blockIdx.x * kSingleStatWaves + wave;
+  if (slot >= numElems) return;  // wave-uniform; no barriers in this kernel
+  const uint32_t b = elemMap ? elemMap[slot] : slot;
 
   uint32_t* bins = sBins + wave * kNumSymbols * S;
 #pragma unroll
@@ -187,13 +190,16 @@ __global__ __launch_bounds__(64) void k_ans_encode_pair(EncodeArgs a) {
   pool.pairs = a.spillPairs;
   pool.pair = kNoSpillPair;
 
-  const uint32_t B = a.numInBatch;
+  // (a.workMap: the elements to pair up, a.numTickets of them, when they are a subset of the batch -- see k_stats_single)
+  const uint32_t B = a.workMap ? a.numTickets : a.numInBatch;
   const uint32_t numPairs = (B + 1u) >> 1;
 #pragma unroll 1
   for (uint32_t p = blockIdx.x; p < numPairs; p += gridDim.x) {
-    const uint32_t bLo = 2u * p, bHi = 2u * p + 1u;
+    const bool haveHi = 2u * p + 1u < B;
+    const uint32_t bLo = a.workMap ? a.workMap[2u * p] : 2u * p;
+    const uint32_t bHi = a.workMap ? (haveHi ? a.workMap[2u * p + 1u] : bLo) : 2u * p + 1u;
     const uint32_t sLo = a.in.size(bLo);
-    const uint32_t sHi = bHi < B ? a.in.size(bHi) : 0u;
+    const uint32_t sHi = haveHi ? a.in.size(bHi) : 0u;
     if ((sLo | sHi) == 0u) continue;  // uniform: two empty elements (their headers are the normalisation's)
     // a half without symbols (empty element, or none at all) follows its neighbour's element: it reads that
     // element's first word, keeps nothing and writes nothing
@@ -331,8 +337,11 @@ __global__ __launch_bounds__(64) void k_ans_decode_pair(DecodeArgs a) {
   const bool upper = lane >= 32u;
   const uint32_t hl = lane & 31u;
   const uint32_t half = upper ? 1u : 0u;
-  const uint32_t B = a.numInBatch;
-  const uint32_t b = 2u * blockIdx.x + half;
+  // (a.workMap, kDecOrderMap: the elements to pair up, a.numListed of them, when they are a subset of the batch)
+  const bool mapped = a.order == kDecOrderMap && a.workMap;
+  const uint32_t B = mapped ? a.numListed : a.numInBatch;
+  const uint32_t slot = 2u * blockIdx.x + half;
+  const uint32_t b = mapped ? a.workMap[slot < B ? slot : B - 1u] : slot;
 
   uint32_t* sLut = (uint32_t*)(smem + 2u * kRingBytes + half * kLutBytes);
   // cdf / pdf of the 256 symbols: in this half's ring, which is not in use before the LUT is complete
@@ -341,7 +350,7 @@ __global__ __launch_bounds__(64) void k_ans_decode_pair(DecodeArgs a) {
   // 2^P symbol marks in the tail of this half's LUT (read back into registers before the first LUT store)
   uint8_t* sMark = (uint8_t*)sLut + kLutBytes - (1u << P);
 
-  bool live = b < B;  // this half still has an element to decode
+  bool live = slot < B;  // this half still has an element to decode
   const uint8_t* archive = nullptr;
   const uint8_t* ans = nullptr;
   uint32_t floatSize = 0, total = 0, nb = 0, totalWords = 0;

@@ -345,6 +345,14 @@ void dgpu_debug_set_decoder_order(int order);
  * lists for every pointer-array call whose sizes differ.  Archives and outputs are byte-identical either way. */
 void dgpu_debug_set_work_lists(int mode);
 
+/* Measurement / test hook: SIZE CLASSES inside one batch.  Upstream sizes the one grid of a call for its largest member
+ * (GpuANSEncode.cuh:753-771, GpuANSDecode.cuh:299-403); here a pointer-array call whose members fall into more than one
+ * of the classes {one block, <= 2, <= 4 (decode: <= 8), more} launches every class on the kernels of its own geometry,
+ * one class after the other on the caller's stream.  -1 (default): when the smaller classes together hold at least 256
+ * members, classes of fewer than 32 joining the next larger one; 0: one geometry per call; 1: every class that has a
+ * member.  Needs the work lists (dgpu_debug_set_work_lists != 0).  Archives and outputs are byte-identical either way. */
+void dgpu_debug_set_size_classes(int mode);
+
 /* Measurement hook: 0 makes every pointer-array call upload its parameter block
  * (no reuse of blocks already resident on the device); 1 (default) restores the
  * cache.  bench.py uses it to report the step time without the cache next to the

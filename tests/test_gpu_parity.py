@@ -1935,3 +1935,55 @@ def test_one_large_tensor_among_many_small_ones(dg):
         finally:
             L.dgpu_debug_set_work_lists(-1)
     assert all(torch.equal(a, b) for a, b in zip(*comps))
+
+
+@pytest.mark.parametrize("mode", [1, -1])
+@pytest.mark.parametrize("ft", [0, O.BFLOAT16, O.FLOAT16, O.FLOAT32])
+def test_size_classes_inside_one_batch(dg, ft, mode):
+    # A batch whose members fall into several size classes -- single blocks, <= 2, <= 4 (decode: <= 8) blocks, more --
+    # runs every class on the kernels of its own geometry, one class after the other (capi.hip, EncodeClass /
+    # DecodeClass).  mode 1: every class that has a member, however few (one large tensor, some of 5-7 blocks, some of
+    # 3-4, some of 2, many single blocks, empty ones); mode -1: the library's policy (classes of fewer than 32 members
+    # join the next larger one; here the 300 single blocks next to the large tensors make it split).  Archives
+    # byte-identical to the oracle, with checksums; decoded through the same mode into capacities that put some members
+    # into ANOTHER class than their size did.
+    L = dg.lib()
+    L.dgpu_debug_set_size_classes(mode)
+    try:
+        rng = np.random.default_rng(4200 + ft)
+        ns = [40 * 4096 + 77, 0, 4096, 1]
+        ns += [int(n) for n in rng.integers(4 * 4096 + 1, 7 * 4096, 5)]
+        ns += [int(n) for n in rng.integers(2 * 4096 + 1, 4 * 4096 + 1, 6)]
+        ns += [int(n) for n in rng.integers(4096 + 1, 2 * 4096 + 1, 7)]
+        ns += [int(n) for n in rng.integers(1, 4097, 300 if mode == -1 else 40)]
+        rng.shuffle(ns)
+        if ft == 0:
+            ws = [np.ascontiguousarray(refgen.generate_symbols(max(n, 1), 20.0 + i % 7)[:n] if i % 5 else
+                                       rng.integers(0, 256, n, dtype=np.uint8)) for i, n in enumerate(ns)]
+            got = gpu_ans_encode(dg, ws, 10, True)
+            for w, g in zip(ws, got):
+                want = O.ans_encode(w, 10, use_checksum=True)
+                assert g.size == want.size and not (g != want).any(), ("raw", w.size)
+            caps = [n + (i % 4) * 3000 for i, n in enumerate(ns)]
+            outs, status, osz = gpu_ans_decode(dg, got, caps, 10, True)
+            assert status.all() and osz.tolist() == ns and all((o[: w.size] == w).all() for o, w in zip(outs, ws))
+        else:
+            dt = np.uint32 if ft == O.FLOAT32 else np.uint16
+            ws = [np.ascontiguousarray(refgen.generate_floats(ft, max(n, 1))[:n] if i % 5 else
+                                       rng.integers(0, 1 << (8 * dt().itemsize), n, dtype=np.uint64).astype(dt), dt) for i, n in enumerate(ns)]
+            ts = [words_to_tensor(ft, w) for w in ws]
+            comp, sizes, _ = dg.compress_data(True, ts, True)
+            hs, hc = sizes.cpu().numpy(), comp.cpu().numpy()
+            arch = []
+            for i, w in enumerate(ws):
+                want = O.float_compress(ft, w, 10, use_checksum=True)
+                assert hs[i] == want.size and not (hc[i, : hs[i]] != want).any(), (ft, w.size)
+                arch.append(comp[i, : hs[i]].clone())
+            outs = [torch.empty((n + (i % 4) * 3000,), dtype=FT_DTYPE[ft], device=DEV) for i, n in enumerate(ns)]
+            status = torch.zeros((len(ns),), dtype=torch.uint8, device=DEV)
+            osz = torch.zeros((len(ns),), dtype=torch.int32, device=DEV)
+            dg.decompress_data(True, arch, outs, True, None, status, osz)
+            assert status.cpu().numpy().all() and osz.cpu().tolist() == ns
+            assert all((tensor_to_words(ft, o[:n]) == w).all() for o, n, w in zip(outs, ns, ws))
+    finally:
+        L.dgpu_debug_set_size_classes(-1)
