@@ -373,6 +373,23 @@ class CompressedExchangePlan:
         self._bind(slot)
         return slot
 
+    def _streams_of_step(self):
+        """(caller's stream, compress stream, decompress stream) of the step being enqueued.  A step of ONE chunk has
+        nothing to overlap between its compress and its decompress side: everything stays on the caller's stream, and
+        the four stream hand-offs of the pipelined form -- an event record, a wait and ~15 us of idle GPU each at world
+        1 -- are not paid (profiles/r06_collective_world1.txt)."""
+        cur = torch.cuda.current_stream(self.dev) if self.on_gpu else None
+        if not self.on_gpu or self.chunks == 1:
+            return cur, cur, cur
+        self.comp_stream.wait_stream(cur)  # the inputs were produced on the caller's stream
+        self.dec_stream.wait_stream(cur)
+        return cur, self.comp_stream, self.dec_stream
+
+    def _join_streams_of_step(self, cur, cs, ds):
+        if self.on_gpu and cs is not cur:
+            cur.wait_stream(cs)
+            cur.wait_stream(ds)
+
     def _round_width(self, nbytes):
         w = (int(nbytes) + 15) // 16 * 16
         return max(min(w, self.cap), min(self.codec.min_width, self.cap))
@@ -473,30 +490,25 @@ class CompressedExchangePlan:
             self._probe_width(shard)
         self._agree_on_width()
         W, world = self.width, self.world
-        cur = torch.cuda.current_stream(self.dev) if self.on_gpu else None
-        if self.on_gpu:
-            self.comp_stream.wait_stream(cur)
-            self.dec_stream.wait_stream(cur)
+        cur, cs, ds = self._streams_of_step()
         works = []
-        with self._on(self.comp_stream):
+        with self._on(cs):
             for k, (lo, hi) in enumerate(self.bounds):
                 m = hi - lo
                 snd = self.send[lo * W : hi * W].view(m, W)
-                self.codec.compress_into(shard[lo:hi], snd, W, self.sizes[lo:hi], self._stream_ptr(self.comp_stream))
+                self.codec.compress_into(shard[lo:hi], snd, W, self.sizes[lo:hi], self._stream_ptr(cs))
                 rcv = self.recv[world * lo * W : world * hi * W]
                 works.append(_all_gather_flat(rcv, snd.view(-1), world))
             self._post_compress()
-        with self._on(self.dec_stream):
+        with self._on(ds):
             for k, (lo, hi) in enumerate(self.bounds):
                 m = hi - lo
                 if works[k] is not None:
                     works[k].wait()
                 rcv = self.recv[world * lo * W : world * hi * W].view(world, m, W)
                 for r in range(world):
-                    self.codec.decompress_from(rcv[r], W, self.out[r, lo:hi], self.status[r, lo:hi], self._stream_ptr(self.dec_stream))
-        if self.on_gpu:
-            cur.wait_stream(self.comp_stream)
-            cur.wait_stream(self.dec_stream)
+                    self.codec.decompress_from(rcv[r], W, self.out[r, lo:hi], self.status[r, lo:hi], self._stream_ptr(ds))
+        self._join_streams_of_step(cur, cs, ds)
 
         status_of_step, out_of_step = self.status, self.out
 
@@ -546,36 +558,31 @@ class CompressedExchangePlan:
             self._probe_width(flat)
         self._agree_on_width()
         W = self.width
-        cur = torch.cuda.current_stream(self.dev) if self.on_gpu else None
-        if self.on_gpu:
-            self.comp_stream.wait_stream(cur)
-            self.dec_stream.wait_stream(cur)
+        cur, cs, ds = self._streams_of_step()
         # chunk k = rows [lo_k, hi_k) of EVERY destination block, so that each chunk is a complete all-to-all
         cb = [shard_range(m, k, min(self.chunks, m)) for k in range(min(self.chunks, m))]
         works = []
         base = 0
-        with self._on(self.comp_stream):
+        with self._on(cs):
             for lo, hi in cb:
                 c = hi - lo
                 snd = self.send[base * W : (base + world * c) * W].view(world, c, W)
                 for j in range(world):
-                    self.codec.compress_into(send[j, lo:hi], snd[j], W, self.sizes[j * m + lo : j * m + hi], self._stream_ptr(self.comp_stream))
+                    self.codec.compress_into(send[j, lo:hi], snd[j], W, self.sizes[j * m + lo : j * m + hi], self._stream_ptr(cs))
                 rcv = self.recv[base * W : (base + world * c) * W]
                 works.append((_all_to_all_flat(rcv, snd.view(-1), world), base, lo, hi))
                 base += world * c
             self._post_compress()
         st = self.status.view(-1)[: world * m].view(world, m)
-        with self._on(self.dec_stream):
+        with self._on(ds):
             for wk, b0, lo, hi in works:
                 c = hi - lo
                 if wk is not None:
                     wk.wait()
                 rcv = self.recv[b0 * W : (b0 + world * c) * W].view(world, c, W)
                 for i in range(world):
-                    self.codec.decompress_from(rcv[i], W, self.out[i, lo:hi], st[i, lo:hi], self._stream_ptr(self.dec_stream))
-        if self.on_gpu:
-            cur.wait_stream(self.comp_stream)
-            cur.wait_stream(self.dec_stream)
+                    self.codec.decompress_from(rcv[i], W, self.out[i, lo:hi], st[i, lo:hi], self._stream_ptr(ds))
+        self._join_streams_of_step(cur, cs, ds)
         if world * m < self.status.numel():
             self.status.view(-1)[world * m :] = 1
         out_of_step = self.out

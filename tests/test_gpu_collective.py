@@ -142,3 +142,57 @@ def test_bench_collective_mode_two_ranks_one_device():
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["bit_exact"] and d["config"]["rows_sent_uncompressed"] == 0
     assert d["config"]["wire_bytes_per_rank"] < d["config"]["per_rank_bytes"]
+
+
+def test_bench_helpers_over_rccl_at_world_one():
+    # bench.py's three collectives on the codec path -- D.max_over_ranks (the step time), D.gather_scalars (every rank's
+    # step time) and D.gather_sizes (the one all-gather of compressed sizes after the timed region) -- through backend
+    # "nccl" (= RCCL) with device tensors: the branch the 2- and 8-rank gloo runs never take.  One rank is what a
+    # one-GPU box offers; the calls, dtypes, devices and shapes are those of N ranks.
+    import torch.distributed as dist
+
+    from dietgpu_amd import distributed as D
+
+    os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    D.init(backend="nccl", device=dev)
+    try:
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        assert D.max_over_ranks(0.125, dev) == 0.125
+        assert D.gather_scalars(0.25, dev) == [0.25]
+        sizes = torch.arange(1, 257, dtype=torch.int32, device=dev)
+        got = D.gather_sizes(sizes, 256)
+        assert got.device.type == "cuda" and torch.equal(got, sizes)
+        assert D.shard_range(256, 0, 1) == (0, 256)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("chunks", [1, 3])
+def test_exchange_plan_stream_forms_agree(chunks):
+    # a plan of ONE chunk runs its step on the caller's stream alone (no hand-offs between a compress and a decompress
+    # stream); more chunks pipeline over three streams.  Same payload either way, and a kernel that follows on the
+    # caller's stream sees the complete output.
+    import torch.distributed as dist
+
+    from dietgpu_amd import distributed as D
+
+    os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    D.init(backend="nccl", device=dev)
+    try:
+        g = torch.Generator(device=dev).manual_seed(3)
+        shard = torch.randn((24, 40_000), generator=g, device=dev).to(torch.bfloat16)
+        plan = D.CompressedAllGatherPlan(shard, chunks=chunks)
+        for _ in range(3):
+            out, redo = plan.all_gather(shard)
+            copy = out.clone()  # (on the caller's stream, right behind the step)
+            torch.cuda.synchronize()
+            assert redo == 0 and torch.equal(copy[0].view(torch.int16), shard.view(torch.int16))
+        h = plan.all_gather_async(shard)
+        out, redo = h.wait(clone=True)
+        assert redo == 0 and torch.equal(out[0].view(torch.int16), shard.view(torch.int16))
+    finally:
+        dist.destroy_process_group()
