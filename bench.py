@@ -302,7 +302,7 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-TRAFFIC_FILES = ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json")
+TRAFFIC_FILES = ("r06_hbm_traffic.json", "r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json")
 
 
 def measured_traffic(workload, kernel):

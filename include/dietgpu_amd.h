@@ -66,7 +66,7 @@ const char* dgpu_version(void);
 /* Bumped whenever an entry point of this header is added, removed or changes its meaning.  Code that is built
  * separately against this header (the tensor-op library of this repository, a cgo / JNI binding) compares the value it was compiled with
  * against the library it finds at run time, so that a stale build fails at load instead of inside a call. */
-#define DGPU_ABI_VERSION 6u
+#define DGPU_ABI_VERSION 7u
 uint32_t dgpu_abi_version(void);
 /* Text of the last error on the calling thread (HIP error string, failed
  * precondition).  The reference aborts through glog CHECK instead. */

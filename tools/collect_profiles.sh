@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copies the outputs of tools/gpu_final.sh <tag> from gpurun_out/ (scratch) into profiles/ (tracked).
-T=${1:-r05}
+T=${1:-r06}
 cd "$(dirname "$0")/.."
 strip() { grep -a -v "amdgpu.ids\|^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path" "$1"; }
 for f in gpurun_out/${T}_bench_*.json gpurun_out/${T}_reference_protocol.json; do

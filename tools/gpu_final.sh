@@ -3,7 +3,7 @@
 # kernel stats of the headline loop alone and of the one-buffer-set loop alone, PMC passes (+ the traffic file stamped
 # with the kernel source hash), timeline, microbenchmarks.
 # Usage: gpurun --timeout 2700 -- bash tools/gpu_final.sh <tag>      (outputs under gpurun_out/; tools/collect_profiles.sh <tag> copies them)
-T=${1:-r05}
+T=${1:-r06}
 mkdir -p gpurun_out
 ( timeout 1500 python -m pytest tests -m gpu -q -n 4 2>&1 | tail -8 ) > gpurun_out/${T}_pytest.txt
 tail -3 gpurun_out/${T}_pytest.txt
