@@ -1347,6 +1347,11 @@ bool histogramLoadsNonTemporal(uint32_t ft) {
 // on the common path: histogram workgroups store partial histograms, the last
 // one of each element sums and normalises them and clears the tile descriptors +
 // ticket for the encode kernel.
+// (DGPU_TWO_LEVEL_LOOKBACK=0: the single level everywhere -- A/B runs and tests)
+std::atomic<int> g_twoLevelLookback{[] {
+  const char* e = getenv("DGPU_TWO_LEVEL_LOOKBACK");
+  return e && *e ? atoi(e) : 1;
+}()};
 struct EncodeShared {
   uint32_t* checksumTemp = nullptr;  // [B] the batch's checksums (computed by the first class's call)
   uint4* table = nullptr;            // [B][256] encoder tables, indexed by the element's own index
@@ -1400,6 +1405,14 @@ int encodeCommon(
   const uint32_t numElems = elemMap ? cls->numElems : B;
   DGPU_ALLOC(tileDesc, uint64_t, arena, lists ? std::max<size_t>(numListedTiles, 1u) : (size_t)B * std::max(maxTiles, 1u));
   DGPU_ALLOC(claims, uint32_t, arena, lists ? std::max<size_t>(numListedTiles, 1u) : (size_t)B * std::max(maxTiles, 1u));
+  // second level of the look-back for elements of more than 64 tiles (kernels_encode.h, lookBackTwoLevel): rectangles only
+  const uint32_t lookbackGroups = (!lists && tileBlocks != kBlocksPerSingleTile && maxTiles > kLookbackGroup && g_twoLevelLookback.load() != 0)
+      ? divUp(maxTiles, kLookbackGroup) : 0u;
+  uint64_t* groupWords = nullptr;
+  if (lookbackGroups) {
+    DGPU_ALLOC(gw, uint64_t, arena, (size_t)B * lookbackGroups * (kGroupArriveStride + 1u));
+    groupWords = gw;
+  }
 
   // The encoder's grid.  `resident` = the workgroups of the kernel that fit on the chip at once.  8-block float tiles
   // run as `resident` persistent workgroups that walk the tickets with a static map; raw bytes and float tiles of 2 / 4
@@ -1450,6 +1463,8 @@ int encodeCommon(
   n.numInBatch = B;
   n.tileBase = tileBaseList;
   n.tileSymbols = tileBlocks * kBlockSize;
+  n.groupWords = groupWords;
+  n.groupWordsPerElement = lookbackGroups * (kGroupArriveStride + 1u);
 
   if (!hist_dev && tileBlocks == kBlocksPerSingleTile && maxTiles > 0 && floatType != kFloat32) {
     // batches of single-block elements: one wavefront counts and normalises an element (kernels_pairs.h); no partial
@@ -1540,6 +1555,8 @@ int encodeCommon(
     e.workMap = lists ? tilesList : elemMap;
     e.tileDesc = tileDesc;
     e.claims = claims;
+    e.groupWords = groupWords;
+    e.groupsPerElement = lookbackGroups;
     e.absentModulo = absentWorkgroupModulo();
     e.spill = spill;
     e.spillFlags = spillFlags;
@@ -2010,6 +2027,7 @@ static size_t encodeTempBytes(uint32_t B, uint32_t maxBytes, uint32_t wordBytes,
   t += alignUp((size_t)B * kNumSymbols * 16, kTempAlign);                         // encoder table
   t += alignUp((size_t)B * tiles * 8, kTempAlign);                                // tile descriptors
   t += alignUp((size_t)B * tiles * 4, kTempAlign);                                // tile claim words
+  if (tiles > kLookbackGroup) t += alignUp((size_t)B * divUp((uint32_t)tiles, kLookbackGroup) * (kGroupArriveStride + 1u) * 8, kTempAlign);  // look-back groups
   if (spills) {
     // spill slots of the persistent encoder workgroups (bounded by what fits on the chip)
     size_t perCu = (160u * 1024u) / encLdsBytes(9, true, kBFloat16, kBlocksPerTile);
@@ -2440,6 +2458,8 @@ int dgpu_ans_calc_weights(
   n.numInBatch = numInBatch;
   n.tileBase = nullptr;
   n.tileSymbols = 0;
+  n.groupWords = nullptr;
+  n.groupWordsPerElement = 0;
   hipLaunchKernelGGL(k_normalize, dim3(numInBatch), dim3(256), 0, (hipStream_t)stream, n);
   DGPU_HIP(hipGetLastError());
   return DGPU_OK;

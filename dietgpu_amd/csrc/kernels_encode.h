@@ -116,6 +116,10 @@ struct EncodeArgs {
   const uint32_t* workMap;   // nullable: [numTickets] element << 16 | tile: the tiles that exist, element by element
   uint64_t* tileDesc;        // [B][maxTiles] (workMap: [numTickets]), zeroed before launch (by the normalisation step)
   uint32_t* claims;          // [maxTiles][B] (workMap: [numTickets]) tile claim words, zeroed before launch
+  // second level of the look-back (lookBackTwoLevel), rectangles with maxTiles > 64 only, else null: per element
+  // groupsPerElement = ceil(maxTiles / 64) arrival words (one per 128 bytes) and as many descriptors, zeroed before launch
+  uint64_t* groupWords;      // [B] x {[groupsPerElement] x kGroupArriveStride arrival words, [groupsPerElement] descriptors}
+  uint32_t groupsPerElement;
   uint32_t absentModulo;     // test hook: workgroups with index % absentModulo == 1 start ~0.5 ms late (0 = off)
   uint16_t* spill;           // kSpill kernels only.  Persistent grids (k_ans_encode, 8-block float tiles): [gridDim.x][blocks
                              // per tile][encSpillSlotWords(P)], a workgroup's slots are its own.  Hardware-dispatched grids
@@ -720,12 +724,16 @@ __device__ __forceinline__ uint32_t encodeRows(
 // `longChains`: the element has more than 16 tiles -- dozens to ~1500 tiles of one element in flight, long waits:
 // the pause starts at its maximum (1 x 128 Mi encode 112.5 -> 105.8 us against the doubling pause, 16 x 8 Mi 119.9 ->
 // 113.1; on 256 x 512 Ki, 16 tiles per element, the doubling pause is the better one by 1 %: profiles/r06_ab_poll_pause_*.txt).
-__device__ __forceinline__ uint32_t lookBackExclusive(const uint64_t* desc, uint32_t tile, uint32_t lane, bool& failed, bool longChains) {
+// `endedAtStart` (nullable): set when the walk went all the way down to index 0 without meeting a real inclusive
+// prefix -- what the caller then holds is the sum of `desc[0 .. tile)` (the second level of lookBackTwoLevel needs to know).
+__device__ __forceinline__ uint32_t lookBackExclusive(const uint64_t* desc, uint32_t tile, uint32_t lane, bool& failed, bool longChains,
+                                                      bool* endedAtStart = nullptr) {
   uint32_t exclusive = 0;
   int base = (int)tile - 1;
+  bool virtualEnd = true;  // (tile 0: nothing to walk)
   while (base >= 0) {
     uint32_t sum = 0;  // aggregates of this lane's descriptors down to (and including) its first inclusive one
-    bool sawIncl = false, sawFailed = false;
+    bool sawIncl = false, sawFailed = false, inclIsVirtual = false;
     uint64_t d[kLookbackPerLane];
 #pragma unroll
     for (int j = 0; j < (int)kLookbackPerLane; ++j) {  // all of the lane's loads in flight at once
@@ -746,17 +754,55 @@ __device__ __forceinline__ uint32_t lookBackExclusive(const uint64_t* desc, uint
       sum += (uint32_t)d[j];
       sawFailed = sawFailed || (d[j] & kDescFailed) != 0ull;
       sawIncl = (d[j] >> 62) == 2;
+      inclIsVirtual = idx < 0;
     }
     const uint64_t inclMask = __ballot(sawIncl);
     const int firstIncl = inclMask ? (__ffsll((unsigned long long)inclMask) - 1) : 64;
     const bool counted = (int)lane <= firstIncl;
     exclusive += waveReduceSum(counted ? sum : 0u);
     failed = failed || __ballot(counted && sawFailed) != 0ull;
-    if (firstIncl < 64) break;
+    if (firstIncl < 64) {
+      virtualEnd = ((__ballot(sawIncl && inclIsVirtual) >> firstIncl) & 1ull) != 0ull;
+      break;
+    }
     base -= 64 * (int)kLookbackPerLane;
   }
+  if (endedAtStart) *endedAtStart = virtualEnd;
   return exclusive;
 }
+
+// Two levels for elements of more than 64 tiles (EncodeArgs::groupWords).  The tiles of an element come in GROUPS of 64.
+// A tile adds its aggregate to its group's arrival word (one 64-bit atomic: sum in the low half, arrivals and failures
+// above it); the tile that completes the group publishes the group's aggregate descriptor, and the group's last tile
+// later upgrades it to the inclusive prefix.  A tile then sums at most 63 tile descriptors of its OWN group and -- if no
+// inclusive prefix lay among them -- the group descriptors below its group down to the nearest inclusive one: two
+// round trips instead of up to tiles / 64 (a 16 Mi-word tensor's 512 tiles finish together in the one round of its
+// call and the last of them walked eight steps back; the reference's own scan is two-level for the same reason,
+// BatchPrefixSum.cuh:69-110).
+constexpr uint32_t kLookbackGroup = 64;
+constexpr uint32_t kGroupArriveStride = 16;  // u64 words between two groups' arrival words (a 128-byte line each)
+__device__ __forceinline__ uint32_t lookBackTwoLevel(const uint64_t* desc, uint64_t* groupArrive, uint64_t* groupDesc, uint32_t tile,
+                                                     uint32_t numTiles, uint32_t aggregate, uint32_t lane, bool& failed) {
+  const uint32_t g = tile / kLookbackGroup, l = tile % kLookbackGroup;
+  const uint32_t groupTiles = (g + 1u) * kLookbackGroup <= numTiles ? kLookbackGroup : numTiles - g * kLookbackGroup;
+  if (lane == 0) {
+    const uint64_t mine = (1ull << 32) | (failed ? (1ull << 48) : 0ull) | (uint64_t)aggregate;
+    const uint64_t prev = __hip_atomic_fetch_add(groupArrive + (size_t)g * kGroupArriveStride, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t now = prev + mine;
+    if (((now >> 32) & 0xffffull) == groupTiles) {
+      // the group is complete.  Its last tile may have published the inclusive prefix already (it only needs the tiles
+      // BEFORE it): never put an aggregate over it
+      uint64_t expected = 0;
+      (void)__hip_atomic_compare_exchange_strong(groupDesc + g, &expected, kDescAggregate | ((now >> 48) ? kDescFailed : 0ull) | (now & 0xffffffffull),
+                                                 __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  bool atGroupStart = false;
+  uint32_t exclusive = lookBackExclusive(desc + (size_t)g * kLookbackGroup, l, lane, failed, true, &atGroupStart);
+  if (atGroupStart && g > 0u) exclusive += lookBackExclusive(groupDesc, g, lane, failed, true);
+  return exclusive;
+}
+
 
 // Persistent workgroups, STATIC tile map with claim words.  Workgroup w owns the
 // tickets w, w + G, w + 2G, ... (G = gridDim.x; ticket t -> element t % B, tile
@@ -996,12 +1042,21 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
         }
 
         bool failed = tileFailed;
-        const uint32_t exclusive = lookBackExclusive(desc, tile, lane, failed, numTiles > 16u);
+        const bool twoLevel = a.groupWords != nullptr && numTiles > kLookbackGroup;  // (uniform)
+        uint64_t* groupArrive = twoLevel ? a.groupWords + (size_t)b * a.groupsPerElement * (kGroupArriveStride + 1u) : nullptr;
+        uint64_t* groupDesc = twoLevel ? groupArrive + (size_t)a.groupsPerElement * kGroupArriveStride : nullptr;
+        const uint32_t exclusive = twoLevel ? lookBackTwoLevel(desc, groupArrive, groupDesc, tile, numTiles, aggregate, lane, failed)
+                                            : lookBackExclusive(desc, tile, lane, failed, numTiles > 16u);
 
         const uint32_t inclusive = exclusive + aggregate;
         if (lane == 0) {
           __hip_atomic_store(&desc[tile], kDescInclusive | (failed ? kDescFailed : 0ull) | (uint64_t)inclusive,
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (twoLevel && (tile % kLookbackGroup == kLookbackGroup - 1u || tile == numTiles - 1u)) {
+            // the group's last tile: its inclusive prefix is the group's
+            __hip_atomic_store(&groupDesc[tile / kLookbackGroup], kDescInclusive | (failed ? kDescFailed : 0ull) | (uint64_t)inclusive,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
           sh->tileBase = exclusive;
           if (tile == numTiles - 1) {
             // complete the header (GpuANSEncode.cuh:533-566)

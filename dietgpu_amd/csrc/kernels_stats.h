@@ -196,6 +196,9 @@ struct NormalizeArgs {
   // that exist only, element by element; element b's begin at tileBase[b], it has ceil(size / tileSymbols) of them
   const uint32_t* tileBase;  // nullable: [numInBatch]
   uint32_t tileSymbols;
+  // second level of the encoder's look-back (EncodeArgs::groupWords), cleared here too; null / 0: none
+  uint64_t* groupWords;      // [numInBatch][groupWordsPerElement]
+  uint32_t groupWordsPerElement;
 };
 
 // The static part of the ANS archive header of element b (the fields ansEncodeCoalesce writes at
@@ -266,6 +269,7 @@ __device__ __forceinline__ void normalizeElement(const NormalizeArgs& a, const u
       a.tileDesc[(size_t)b * a.maxTiles + i] = 0;
       if (a.claims) a.claims[(size_t)i * a.numInBatch + b] = 0;
     }
+    for (uint32_t i = tid; i < a.groupWordsPerElement; i += 256u) a.groupWords[(size_t)b * a.groupWordsPerElement + i] = 0;
   }
 
   if (total != 0) {
