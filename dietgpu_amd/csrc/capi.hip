@@ -1091,8 +1091,8 @@ std::atomic<int> g_sizeClasses{[] {
 // Splits the batch into size classes (false: one geometry for the call, as before).  `classOf(size)` -> blocks per tile /
 // workgroup of an element of that size; `pairsOk`: the single-block class has kernels of its own (not float32 encode).
 template <typename ClassOf>
-bool classifyBySize(const std::vector<uint32_t>& sizes, ClassOf classOf, bool pairsOk, uint32_t largestClass,
-                    std::vector<uint32_t>* classOfElem, std::vector<uint32_t>* classesOut) {
+bool classifyBySize(const std::vector<uint32_t>& sizes, ClassOf classOf, bool pairsOk, std::vector<uint32_t>* classOfElem,
+                    std::vector<uint32_t>* classesOut) {
   const int mode = g_sizeClasses.load();
   const size_t B = sizes.size();
   if (mode == 0 || g_workLists.load() == 0 || B < 2 || B > 65535u) return false;
@@ -1124,18 +1124,15 @@ bool classifyBySize(const std::vector<uint32_t>& sizes, ClassOf classOf, bool pa
     if (kv.first != count.rbegin()->first) small += kv.second;
   }
   if (mode != 1 && small < kMinSplitElements) return false;
-  (void)largestClass;
   classesOut->clear();
   for (auto it = count.rbegin(); it != count.rend(); ++it) classesOut->push_back(it->first);  // large elements first
   return true;
 }
 bool planEncodeClasses(const std::vector<uint32_t>& sizes, uint32_t floatType, std::vector<EncodeClass>* classes, std::vector<uint32_t>* work) {
   std::vector<uint32_t> classOfElem, order;
-  if (!classifyBySize(sizes, [](uint32_t sz) { return encTileBlocksFor(sz); }, floatType != kFloat32, kBlocksPerTile, &classOfElem, &order)) return false;
+  if (!classifyBySize(sizes, [](uint32_t sz) { return encTileBlocksFor(sz); }, floatType != kFloat32, &classOfElem, &order)) return false;
   const size_t B = sizes.size();
   const uint32_t wordBytes = floatType ? floatWordBytes(floatType) : 1u;
-  uint64_t totalBytes = 0;
-  for (uint32_t sz : sizes) totalBytes += (uint64_t)sz * wordBytes;
   classes->clear();
   for (uint32_t c : order) {
     EncodeClass k;
@@ -1153,7 +1150,7 @@ bool planEncodeClasses(const std::vector<uint32_t>& sizes, uint32_t floatType, s
       work->insert(work->end(), elems.begin(), elems.end());
     } else {
       // tiles element by element, the class's larger elements first; histogram parts sized for the usual number of
-      // workgroups over the WHOLE batch (the classes run one after the other, each should fill the chip)
+      // workgroups over the CLASS (the classes run one after the other, each should fill the chip)
       std::stable_sort(elems.begin(), elems.end(), [&](uint32_t x, uint32_t y) { return sizes[x] > sizes[y]; });
       const uint32_t tileSymbols = c * kBlockSize;
       std::vector<uint32_t> tileBase(B, 0u);
@@ -1190,7 +1187,6 @@ bool planEncodeClasses(const std::vector<uint32_t>& sizes, uint32_t floatType, s
     }
     classes->push_back(k);
   }
-  (void)totalBytes;
   return true;
 }
 
@@ -1203,7 +1199,7 @@ struct DecodeClass {
 uint32_t decTileBlocksFor(uint32_t maxBlocks);
 bool planDecodeClasses(const std::vector<uint32_t>& caps, std::vector<DecodeClass>* classes, std::vector<uint32_t>* work) {
   std::vector<uint32_t> classOfElem, order;
-  if (!classifyBySize(caps, [](uint32_t cap) { return decTileBlocksFor(divUp(cap, kBlockSize)); }, true, 16u, &classOfElem, &order)) return false;
+  if (!classifyBySize(caps, [](uint32_t cap) { return decTileBlocksFor(divUp(cap, kBlockSize)); }, true, &classOfElem, &order)) return false;
   const size_t B = caps.size();
   classes->clear();
   for (uint32_t c : order) {
@@ -1355,6 +1351,8 @@ std::atomic<int> g_twoLevelLookback{[] {
 struct EncodeShared {
   uint32_t* checksumTemp = nullptr;  // [B] the batch's checksums (computed by the first class's call)
   uint4* table = nullptr;            // [B][256] encoder tables, indexed by the element's own index
+  uint16_t* spill = nullptr;         // spill slots of the float encoders (every class's kernel is done with them when the next starts)
+  size_t spillWords = 0;
 };
 int encodeCommon(
     TempArena& arena, StreamLease& lease, hipStream_t stream, int P, bool useChecksum, uint32_t B,
@@ -1398,7 +1396,7 @@ int encodeCommon(
   const uint32_t numListedHistParts = !lists ? 0u : (cls ? cls->numHistParts : plan->numHistParts);
   const uint32_t listedHistPartBytes = !lists ? 0u : (cls ? cls->histPartBytes : plan->histPartBytes);
   const uint32_t* tilesList = !lists ? nullptr : (cls ? work_dev + cls->tilesAt : work_dev);
-  const uint32_t* histList_ = !lists ? nullptr : (cls ? work_dev + cls->histAt : work_dev + (size_t)plan->numTiles);
+  const uint32_t* histPartsList = !lists ? nullptr : (cls ? work_dev + cls->histAt : work_dev + (size_t)plan->numTiles);
   const uint32_t* tileBaseList = !lists ? nullptr : (cls ? work_dev + cls->tileBaseAt : work_dev + (size_t)plan->numTiles + plan->numHistParts);
   // (the single-block class of a batch: the elements to pair up)
   const uint32_t* elemMap = (cls && tileBlocks == kBlocksPerSingleTile) ? work_dev + cls->elemsAt : nullptr;
@@ -1428,8 +1426,16 @@ int encodeCommon(
   if (maxTiles > 0 && encodeSpills(floatType)) {
     // (single-block batches: two slots per workgroup, one per element of its pair)
     const uint32_t slotsPerWg = tileBlocks == kBlocksPerSingleTile ? 2u : tileBlocks;
-    DGPU_ALLOC(sp, uint16_t, arena, (size_t)resident * slotsPerWg * encSpillSlotWords(P));
-    spill = sp;
+    // (the size classes of one call run one after the other on the stream: they share the region of the first one
+    // that is large enough)
+    const size_t spillWords = (size_t)resident * slotsPerWg * encSpillSlotWords(P);
+    if (shared && shared->spill && shared->spillWords >= spillWords) {
+      spill = shared->spill;
+    } else {
+      DGPU_ALLOC(sp, uint16_t, arena, spillWords);
+      spill = sp;
+      if (shared) shared->spill = sp, shared->spillWords = spillWords;
+    }
     if (tileBlocks == kBlocksPerSingleTile || hwDispatch) {
       // one workgroup per pair / tile: the slots are a POOL with a pair for every wavefront that can be resident,
       // handed out through library-owned flags that are zero at rest
@@ -1496,7 +1502,7 @@ int encodeCommon(
       histTemp = ht;
     }
     HistFuse fuse;
-    fuse.workMap = histList ? histList_ : nullptr;
+    fuse.workMap = histList ? histPartsList : nullptr;
     fuse.partBytes = histList ? listedHistPartBytes : 0u;
     uint32_t* acc = nullptr;
     int rc = arrivalCounters(lease, &fuse.arrive, &acc);
