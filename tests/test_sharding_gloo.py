@@ -272,6 +272,13 @@ def _plan_worker(rank, world, port, q):
     for r in range(world):
         ok = ok and torch.equal(out[r].view(torch.int16), shard_of(r, steps[-1][0], {}).view(torch.int16))
     ok = ok and redos == [0, (1 if rank == 0 else 0), 0, 0] and handles[1].wait()[1] == redos[1]  # (wait is idempotent)
+    # wait(clone=True): an output of the caller's own, which outlives the buffer set's reuse by step k + depth
+    kept, _ = handles[-1].wait(clone=True)
+    ok = ok and kept.data_ptr() != out.data_ptr() and torch.equal(kept.view(torch.int16), out.view(torch.int16))
+    for extra in range(2):
+        plan3.all_gather_async(shards[extra]).wait()
+    for r in range(world):
+        ok = ok and torch.equal(kept[r].view(torch.int16), shard_of(r, steps[-1][0], {}).view(torch.int16))
     log.append(tuple(redos))
     dist.barrier()
     q.put((rank, ok, log))
