@@ -443,6 +443,8 @@ def run_collective(args, data, ft, desc, world, rank, device, D):
         dist.all_gather(out, data)
         return out
 
+    if not args.chunks:
+        args.chunks = 1 if world == 1 else 4
     plan = D.CompressedAllGatherPlan(data, chunks=args.chunks)
 
     def compressed():
@@ -636,7 +638,9 @@ def main():
     ap.add_argument("--collective", action="store_true",
                     help="instead of the codec step: plain vs compressed all-gather of every rank's shard "
                          "(dietgpu_amd.distributed.CompressedAllGatherPlan), effective GB/s per rank")
-    ap.add_argument("--chunks", type=int, default=4, help="--collective: pipeline chunks per shard")
+    ap.add_argument("--chunks", type=int, default=0,
+                    help="--collective: pipeline chunks per shard (default: 4 over a link, 1 at world 1, where a step has "
+                         "nothing to overlap and stays on the caller's stream)")
     ap.add_argument("--rotate", type=int, default=4,
                     help="distinct {input, archive, output} buffer sets of the headline (cache-cold) loop; "
                          "1 = re-code one buffer set (the memory-side cache then serves half the traffic)")
