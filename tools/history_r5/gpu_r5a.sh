@@ -4,7 +4,7 @@
 #   encoder dispatch (persistent vs one workgroup per tile) on 4 shapes, v_r4.so = the round-4 tree;
 #   single-block elements: pair encoder table build, k_stats_single bins (8/16/32 slots, 1 or 4 waves per workgroup,
 #   hot symbol in a register); small tiles: the decoder's scan LUT build.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 timeout 900 python -m pytest tests -m gpu -q -x -n 4 2>&1 | tail -15 > $O/r5a_pytest.txt
 grep -a "passed\|failed\|error" $O/r5a_pytest.txt | tail -3

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, pass aa: work lists for batches whose elements differ widely in size (capi.hip, RaggedPlan): the new parity
 # tests, the GPU suite, then tools/ragged_probe.py with the lists (default) and with the rectangles (DGPU_WORK_LISTS=0).
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "widely_different or one_large_tensor" 2>&1 | tail -15 > $O/r5aa_pytest_lists.txt
 tail -6 $O/r5aa_pytest_lists.txt

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, pass ab: from how much emptiness in the rectangle do the work lists pay?  tools/ragged_probe.py's batches of
 # merely varying sizes under the rectangles (0), the lists forced (1) and the policy (default).
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 for m in 0 1 default; do
   echo "## DGPU_WORK_LISTS=$m"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, pass ac: the encoder's work list element by element (descriptors and claim words for the listed tiles only):
 # the list tests, the GPU suite, tools/ragged_probe.py under the policy, the rectangles (0) and the lists forced (1).
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "widely_different or one_large_tensor" 2>&1 | tail -15 > $O/r5ac_pytest_lists.txt
 tail -3 $O/r5ac_pytest_lists.txt

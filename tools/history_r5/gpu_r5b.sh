@@ -2,7 +2,7 @@
 # Round 5, pass b: the tree after pass a (raw-byte encoder dispatched by the hardware, pair encoder table build, small-tile
 # LUT build): whole GPU suite (incl. the reference's own Python tests from oracle/_ref/reference_python_tests), smoke,
 # the driver's bench command with the compact lines of BASELINE configs 2 and 4.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 timeout 900 python -m pytest tests -m gpu -q -n 4 2>&1 | tail -25 > $O/r5b_pytest.txt
 tail -5 $O/r5b_pytest.txt

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, pass c: (1) raw bytes: slices of the compress call on two streams, so that histogram(k+1) overlaps encode(k);
 # (2) decoder grid in tile-major order (v_dectm.so: the order the encoder writes the archives in) against element-major.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 timeout 600 python tools/slice_streams_u8_experiment.py > $O/r5c_slice_streams_u8.txt 2>&1
 tail -10 $O/r5c_slice_streams_u8.txt

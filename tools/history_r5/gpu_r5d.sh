@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, pass d: order of k_ans_decode's workgroups (DGPU_DEC_ORDER: 0 element-major, 1 tile-major, 2 per-XCD element-major):
 # parity under every order, then the A/B over shapes.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 for o in 1 2; do
   DGPU_DEC_ORDER=$o timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_cabi.py -m gpu -q -n 4 2>&1 | tail -4 > $O/r5d_pytest_order$o.txt

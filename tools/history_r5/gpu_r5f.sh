@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, pass f: histogram workgroups stream one contiguous part of their element (base) against parts interleaved at
 # 4 KiB (v_r5e.so = the tree before): statistics parity, then the A/B over shapes.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_cabi.py tests/test_reference_pin.py -m gpu -q -n 4 2>&1 | tail -3 > $O/r5f_pytest.txt
 tail -1 $O/r5f_pytest.txt

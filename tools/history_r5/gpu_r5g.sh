@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, pass g: why is the float encoder 40 % slower on few large elements?  Timing ablation (WRONG archives by design,
 # DGPU_BENCH_ABLATION=1 skips bench.py's checks): v_abl_nolookback.so never waits for a predecessor's descriptor.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 export DGPU_BENCH_ABLATION=1
 for shape in "256 524288" "16 8388608" "1 134217728"; do

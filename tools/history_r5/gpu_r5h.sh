@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, pass h: k_ans_encode_pair launched one workgroup per pair (v_pairhw.so; its spill slots then come from an
 # oversized temp region: experiment only) against the persistent grid; kernel trace of a 1 Mi-float compress + decompress.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 AB_ARGS="--batch 32768 --elems 4096" AB_STEPS=50 timeout 300 tools/ab.sh 3 bf16 base v_pairhw.so > $O/r5h_ab_pair_encoder_hw_dispatch_bf16.txt 2>&1
 cut -c1-250 $O/r5h_ab_pair_encoder_hw_dispatch_bf16.txt | tail -8

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, pass i: k_ans_encode_pair one workgroup per pair with pooled spill slots (base) against the persistent grid
 # (v_r5e.so): whole GPU suite, then the A/B on batches of single-block elements.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 timeout 1200 python -m pytest tests -m gpu -q -n 4 2>&1 | tail -25 > $O/r5i_pytest.txt
 tail -4 $O/r5i_pytest.txt

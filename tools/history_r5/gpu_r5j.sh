@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, pass j: float batches of small elements (2- and 4-block tiles), k_ans_encode as one workgroup per tile
 # (v_smallhw.so with DGPU_ENC_DISPATCH=1: experiment with oversized static spill slots) against the persistent grid.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 for shape in "16384 8192" "8192 16384" "4096 32768" "2048 65536"; do
   set -- $shape

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, pass k: float tiles of 2 / 4 blocks under hardware dispatch with pooled spill slots (base; forced persistent
 # with DGPU_ENC_DISPATCH=0): whole GPU suite, then the A/B.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 timeout 1200 python -m pytest tests -m gpu -q -n 4 2>&1 | tail -25 > $O/r5k_pytest.txt
 tail -4 $O/r5k_pytest.txt

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, pass m: compressed exchange with the host read of step k behind the launch of step k + 1 (plan depth 2):
 # collective tests, then bench.py --collective at world 1.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 timeout 900 python -m pytest tests/test_gpu_collective.py tests/test_gpu_bench.py -m gpu -q 2>&1 | tail -5
 python bench.py --collective --no-cpu-baseline --chunks 1 --steps 100 --warmup 10 2>/dev/null | grep "^{" > $O/r5m_bench_collective_world1.json

@@ -2,7 +2,7 @@
 # Round 5, pass n: float encoder, wavefront priority by position in the round (v_prio: the first quarter of the persistent grid
 # runs at s_setprio 3, the last at 0; v_priorev: the reverse) -- does a deliberate skew between a tile and its predecessors
 # shorten the look-back wait of few large elements?
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 for shape in "1 134217728" "16 8388608" "256 524288"; do
   set -- $shape

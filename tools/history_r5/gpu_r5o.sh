@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, pass o: whole GPU suite once more (refreshes the evidence run's pytest file), PMC passes of the shapes whose kernels
 # changed this round (single-block pairs, small tiles, few large elements) and the digest over all of them.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 ( timeout 1500 python -m pytest tests -m gpu -q -n 4 2>&1 | tail -8 ) > $O/r05_pytest.txt
 tail -2 $O/r05_pytest.txt

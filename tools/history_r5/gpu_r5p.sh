@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 5, pass p: lane slots per bin of the histogram workgroups that see <= 64 KiB (batches of small elements): 4 / 8 (ships) / 16.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 for shape in "16384 8192" "8192 16384" "4096 32768"; do
   set -- $shape

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 5, pass q: as pass p with 32 lane slots too, plus the shapes around the 64 KiB-per-workgroup switch.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 for shape in "16384 8192" "8192 16384" "4096 32768" "32768 6000"; do
   set -- $shape

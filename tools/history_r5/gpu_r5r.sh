@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, pass r: (1) the batch size from which the decoder's workgroups go per XCD: 32 x 4 Mi and 48 x 2.67 Mi under order 0 / 2;
 # (2) histogram workgroups per element now that parts are contiguous: 512 (ships) / 768 / 1024 target workgroups.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 for shape in "32 4194304" "48 2796200" "40 3355440"; do
   set -- $shape

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, pass t: the chunked encoder path for blocks that are not full (encodeRows kTail; base) against the scalar path
 # (v_pre_tail.so): whole GPU suite, then element sizes that are not whole tiles, and batches of small ragged elements.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 timeout 1200 python -m pytest tests -m gpu -q -n 4 2>&1 | tail -6 > $O/r5t_pytest.txt
 tail -3 $O/r5t_pytest.txt

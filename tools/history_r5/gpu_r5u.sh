@@ -2,7 +2,7 @@
 # Round 5, pass u: blocks that are not full on the chunked / straight-line paths of BOTH coders (encodeRows kTail,
 # decodeBlock kTail; base) against the scalar paths (v_pre_tail.so): whole GPU suite, then element sizes that are not
 # whole tiles and batches of small ragged elements.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 timeout 1200 python -m pytest tests -m gpu -q -n 4 2>&1 | tail -12 > $O/r5u_pytest.txt
 tail -6 $O/r5u_pytest.txt

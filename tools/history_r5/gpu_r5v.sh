@@ -2,7 +2,7 @@
 # Round 5, pass v: the decoder's partial-block path with the top rows' non-compressed bytes requested eight rows at a
 # time (base) against one row at a time (v_tail1.so) and against the scalar paths (v_pre_tail.so): the GPU parity
 # tests, then the shapes of pass u.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 timeout 1200 python -m pytest tests -m gpu -q -n 4 2>&1 | tail -12 > $O/r5v_pytest.txt
 tail -6 $O/r5v_pytest.txt

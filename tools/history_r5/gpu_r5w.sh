@@ -2,7 +2,7 @@
 # Round 5, pass w: the decoder's partial-block path with the groups above the whole ones run by the predicated form of
 # the SAME pipelined group loop (base), against the top rows eight at a time without cross-group prefetch
 # (v_tail2.so) and the scalar paths (v_pre_tail.so): the GPU parity tests, then the shapes of passes u and v.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 timeout 1200 python -m pytest tests -m gpu -q -n 4 2>&1 | tail -12 > $O/r5w_pytest.txt
 tail -6 $O/r5w_pytest.txt

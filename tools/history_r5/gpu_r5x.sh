@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, pass x: pass w's decoder with the rows of the top group that neither half has skipped (base) against pass
 # w's (v_tail3.so) and the scalar paths (v_pre_tail.so): the GPU parity tests, then batches of small ragged elements.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 timeout 1200 python -m pytest tests -m gpu -q -n 4 2>&1 | tail -12 > $O/r5x_pytest.txt
 tail -3 $O/r5x_pytest.txt

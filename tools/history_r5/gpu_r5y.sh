@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, pass y: what elements that are not 16-byte aligned cost (rows of a [B, n] matrix with n * 2 bytes not a multiple of
 # 16: every row but each eighth starts between vector boundaries): 256 x 530000 (aligned) / 530004 (8-byte) / 530001 (2-byte).
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 for w in "bf16 256 530000" "bf16 256 530004" "bf16 256 530001" "bf16 32768 4001" "fp32 256 530002"; do
   set -- $w

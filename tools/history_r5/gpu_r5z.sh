@@ -3,7 +3,7 @@
 # alignment with the straddling part loaded as the 16 bytes that end at the element's end, decoder wide stores at any word
 # alignment; base) against the 16-byte-aligned-only forms (v_aligned_only.so): the new alignment sweep, the GPU suite, then
 # rows of [B, n] matrices whose row length is not a multiple of 16 bytes.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "every_word_alignment or unaligned or split_size or partial_last" 2>&1 | tail -8 > $O/r5z_pytest_alignment.txt
 tail -4 $O/r5z_pytest_alignment.txt

@@ -2,7 +2,7 @@
 # Round 6, pass a (exploration): what the box exposes of its clocks; the driver's bench command under a kernel trace with
 # the clocks sampled beside it; where a 2-128 MiB call's time goes; look-back windows of 256 / 512 predecessors per round
 # trip; the float encoder at 5 / 4 / 3 workgroups per CU.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out
 python tools/clock_sampler.py --probe > $O/r6a_clock_probe.txt 2>&1
 ( which amd-smi rocm-smi; timeout 20 rocm-smi --showclocks 2>&1 | head -30 ) >> $O/r6a_clock_probe.txt 2>&1

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6, pass b: the transient after load begins (copy kernel vs codec step); the driver's command under a kernel trace
 # again with the steady-state window chosen correctly; the timeline of small calls; look-back polling back-off.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out
 python tools/transient_probe.py > $O/r6b_transient_probe.txt 2>/tmp/e0.txt || tail -3 /tmp/e0.txt
 cat $O/r6b_transient_probe.txt

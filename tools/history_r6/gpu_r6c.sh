@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6, pass c: look-back polling back-off, longer sleeps and the shapes with short chains.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 for shape in "1 134217728" "16 8388608" "64 2097152" "256 524288"; do
   set -- $shape

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6, pass d: the one-kernel float compress (k_float_compress_fused): parity tests, then fused against the
 # two-kernel path (DGPU_FUSED=1 / 0) on the headline shape, few large tensors and small calls.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 ( timeout 900 python -m pytest tests/test_gpu_fused.py -x -q 2>&1 | tail -15 ) > $O/r6d_pytest_fused.txt
 cat $O/r6d_pytest_fused.txt

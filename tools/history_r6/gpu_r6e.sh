@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6, pass e: fused kernel after the header fix: parity, A/B against the two-kernel path; poll back-off doubling vs fixed.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 ( timeout 900 python -m pytest tests/test_gpu_fused.py -x -q 2>&1 | tail -15 ) > $O/r6e_pytest_fused.txt
 cat $O/r6e_pytest_fused.txt

@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 R=$PWD
 python - <<'PY'
 import torch

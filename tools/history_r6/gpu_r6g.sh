@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6, pass g: where the one-kernel compress wins: single tensors of 0.5 .. 32 Mi words, and small batches.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 for mode in 0 1; do
   DGPU_FUSED=$mode python tools/small_call_probe.py --sizes 0.5,1,2,4,8,16 --reps 200 > $O/r6g_rates_b1_fused$mode.txt 2>/dev/null

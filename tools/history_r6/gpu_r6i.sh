@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6, pass i: the pause between two polls of an unpublished look-back descriptor: doubling from 0.2 us (base), doubling
 # from 0.85 us, fixed 3.4 us -- few large tensors, the headline shape, and small calls (two-kernel path throughout).
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 export DGPU_FUSED=0
 for shape in "1 134217728" "16 8388608" "256 524288"; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6, pass j: the histogram's atomic counters of one or two large elements in 16 / 8 sets (base) against one set;
 # the look-back pause by chain length; the whole GPU suite on the tree.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 export DGPU_FUSED=0
 for shape in "1 134217728" "1 16777216" "2 8388608"; do

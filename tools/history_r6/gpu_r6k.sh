@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6, pass k: look-back pause by chain length (base) against always-maximum and always-doubling.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 export DGPU_FUSED=0
 for shape in "16 8388608" "1 134217728" "64 2097152" "256 524288"; do

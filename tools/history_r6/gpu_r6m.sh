@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6, pass m: the whole GPU suite on the tree (size classes, one-stream collective steps, RCCL helpers at world 1);
 # the compressed all-gather at world 1 with one chunk and with four.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 ( timeout 1500 python -m pytest tests -m gpu -q -n 4 2>&1 | tail -8 ) > $O/r6m_pytest.txt
 tail -4 $O/r6m_pytest.txt

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6, pass n: two-level look-back (groups of 64 tiles) for elements of more than 64 tiles: parity, then on / off.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 ( timeout 1200 python -m pytest tests/test_gpu_parity.py -x -q -k "lookback or absent_workgroups or one_gi or baseline_config or dispatch_modes or capacity" 2>&1 | tail -6 ) > $O/r6n_pytest_lookback.txt
 cat $O/r6n_pytest_lookback.txt

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6, pass o: float histogram with 8 / 16 loads of 16 bytes in flight per lane instead of 4.
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && export TMPDIR=/tmp
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && export TMPDIR=/tmp
 O=gpurun_out
 for shape in "1 16777216" "1 1048576" "256 524288" "16384 8192" "1 134217728"; do
   set -- $shape
