@@ -1,6 +1,7 @@
-"""Latency of the stand-alone normalisation of ONE element (k_normalize) next to the smallest kernel there is, events around\neach launch.  Round 6 on MI355X: 6.2 us both -- the floor of a launch, not work.  Usage (GPU box): python tools/norm_latency.py"""
+"""Latency of the stand-alone normalisation of ONE element (k_normalize) next to the smallest kernel there is, events around
+each launch.  Round 6 on MI355X: 6.2 us both -- the floor of a launch, not work.  Usage (GPU box): python tools/norm_latency.py"""
 import ctypes as C, sys, statistics, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, ".")
 import dietgpu_amd as dg
 dev = torch.device("cuda", 0); L = dg.lib()
 x = torch.randn(1, 1 << 20, device=dev).to(torch.bfloat16).view(torch.int16).to(torch.int32)
