@@ -846,6 +846,23 @@ uint32_t encodeGridPFT(uint32_t tickets) {
   }();
   return std::max(1u, std::min(tickets, perCu * numComputeUnits()));
 }
+// ... the persistent 8-block bf16 / fp32 encoder with the wide stage (kernels_encode.h, kSpillStageWordsWide)
+template <int P, uint32_t FT>
+uint32_t encodeGridWidePF(uint32_t tickets) {
+  if constexpr (FT == kBFloat16 || FT == kFloat32) {
+    static const uint32_t perCu = [] {
+      int n = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (k_ans_encode<P, FT, true, kBlocksPerTile, true, true>), encThreads(kBlocksPerTile),
+                                                       encLdsBytes(P, true, FT, kBlocksPerTile, true)) != hipSuccess || n < 1) {
+        n = 1;
+      }
+      return (uint32_t)n;
+    }();
+    return std::max(1u, std::min(tickets, perCu * numComputeUnits()));
+  } else {
+    return encodeGridPFT<P, FT, kBlocksPerTile>(tickets);
+  }
+}
 // Batches of single-block elements: two ELEMENTS per wavefront (kernels_pairs.h) instead of one with an idle half.
 template <int P, uint32_t FT>
 uint32_t encodePairGridPF(uint32_t elements) {
@@ -862,16 +879,25 @@ uint32_t encodePairGridPF(uint32_t elements) {
   return std::max(1u, std::min((elements + 1u) / 2u, perCu * numComputeUnits()));
 }
 template <int P, uint32_t FT>
-uint32_t encodeGridPF(uint32_t tickets, uint32_t tileBlocks) {
+uint32_t encodeGridPF(uint32_t tickets, uint32_t tileBlocks, bool wide) {
   if (tileBlocks == kBlocksPerSingleTile) return encodePairGridPF<P, FT>(tickets);  // (one ticket per element)
+  if (wide && tileBlocks == kBlocksPerTile) return encodeGridWidePF<P, FT>(tickets);
   return tileBlocks == kBlocksPerTinyTile ? encodeGridPFT<P, FT, kBlocksPerTinyTile>(tickets)
       : tileBlocks == kBlocksPerSmallTile ? encodeGridPFT<P, FT, kBlocksPerSmallTile>(tickets)
                                           : encodeGridPFT<P, FT, kBlocksPerTile>(tickets);
 }
 
 template <int P, uint32_t FT, bool kPersistent>
-int launchEncodePFD(const EncodeArgs& a, uint32_t tileBlocks, uint32_t grid, hipStream_t stream) {
+int launchEncodePFD(const EncodeArgs& a, uint32_t tileBlocks, uint32_t grid, bool wide, hipStream_t stream) {
   constexpr bool kSpill = encodeSpills(FT);
+  if constexpr (FT == kBFloat16 || FT == kFloat32) {
+    if (wide && tileBlocks == kBlocksPerTile) {
+      DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT, true, kBlocksPerTile, true, true>), dim3(grid), dim3(kBlocksPerTile * 32),
+                  encLdsBytes(P, true, FT, kBlocksPerTile, true), stream, a);
+      DGPU_HIP(hipGetLastError());
+      return DGPU_OK;
+    }
+  }
   if (tileBlocks == kBlocksPerTinyTile) {
     DGPU_LAUNCH("k_ans_encode", stream, (k_ans_encode<P, FT, kSpill, kBlocksPerTinyTile, kPersistent>), dim3(grid), dim3(kBlocksPerTinyTile * 32),
                 encLdsBytes(P, kSpill, FT, kBlocksPerTinyTile), stream, a);
@@ -889,15 +915,15 @@ int launchEncodePFD(const EncodeArgs& a, uint32_t tileBlocks, uint32_t grid, hip
 }
 // `hwDispatch`: grid == a.numTickets, one workgroup per tile (k_ans_encode<..., kPersistent = false>)
 template <int P, uint32_t FT>
-int launchEncodePF(const EncodeArgs& a, uint32_t tileBlocks, uint32_t grid, bool hwDispatch, hipStream_t stream) {
+int launchEncodePF(const EncodeArgs& a, uint32_t tileBlocks, uint32_t grid, bool hwDispatch, bool wide, hipStream_t stream) {
   constexpr bool kSpill = encodeSpills(FT);
   if (tileBlocks == kBlocksPerSingleTile) {
     DGPU_LAUNCH("k_ans_encode_pair", stream, (k_ans_encode_pair<P, FT, kSpill>), dim3(grid), dim3(64), encPairLdsBytes(P, kSpill, FT), stream, a);
     DGPU_HIP(hipGetLastError());
     return DGPU_OK;
   }
-  if (hwDispatch) return launchEncodePFD<P, FT, false>(a, tileBlocks, grid, stream);
-  return launchEncodePFD<P, FT, true>(a, tileBlocks, grid, stream);
+  if (hwDispatch) return launchEncodePFD<P, FT, false>(a, tileBlocks, grid, wide, stream);
+  return launchEncodePFD<P, FT, true>(a, tileBlocks, grid, wide, stream);
 }
 
 #define DGPU_ENCODE_DISPATCH(P_, FT_, EXPR)                                   \
@@ -924,15 +950,22 @@ int launchEncodePF(const EncodeArgs& a, uint32_t tileBlocks, uint32_t grid, bool
       break;                                                                  \
   }
 
-uint32_t encodeGrid(int P, uint32_t ft, uint32_t tileBlocks, uint32_t tickets) {
+uint32_t encodeGrid(int P, uint32_t ft, uint32_t tileBlocks, uint32_t tickets, bool wide) {
   uint32_t g = 1;
-  DGPU_ENCODE_DISPATCH(P, ft, g = (encodeGridPF<kP, kFT>(tickets, tileBlocks)));
+  DGPU_ENCODE_DISPATCH(P, ft, g = (encodeGridPF<kP, kFT>(tickets, tileBlocks, wide)));
   return g;
 }
+// The wide stage (five workgroups per CU, no flushes on N(0,1) exponents) for persistent 8-block bf16 / fp32 tiles of
+// batches whose elements have few tiles; elements of many tiles keep six workgroups per CU in flight behind their
+// in-order commit (kernels_encode.h, kSpillStageWordsWide; profiles/r06_ab_encoder_five_per_cu_*.txt).
+constexpr uint32_t kWideStageMaxTiles = 32;
+bool encoderWideStage(uint32_t floatType, uint32_t tileBlocks, uint32_t maxTiles) {
+  return (floatType == kBFloat16 || floatType == kFloat32) && tileBlocks == kBlocksPerTile && maxTiles <= kWideStageMaxTiles;
+}
 
-int launchEncode(int P, uint32_t ft, const EncodeArgs& a, uint32_t tileBlocks, uint32_t grid, bool hwDispatch, hipStream_t stream) {
+int launchEncode(int P, uint32_t ft, const EncodeArgs& a, uint32_t tileBlocks, uint32_t grid, bool hwDispatch, bool wide, hipStream_t stream) {
   int rc = DGPU_OK;
-  DGPU_ENCODE_DISPATCH(P, ft, rc = (launchEncodePF<kP, kFT>(a, tileBlocks, grid, hwDispatch, stream)));
+  DGPU_ENCODE_DISPATCH(P, ft, rc = (launchEncodePF<kP, kFT>(a, tileBlocks, grid, hwDispatch, wide, stream)));
   return rc;
 }
 
@@ -1418,7 +1451,8 @@ int encodeCommon(
   // (encoderHardwareDispatch); k_ans_encode_pair always runs one workgroup per pair.  Spill slots (float inputs):
   // [resident][slots per workgroup] -- a persistent workgroup's own, or a pool handed out through spillFlags.
   const uint32_t numTickets = lists ? numListedTiles : (elemMap ? numElems : B * maxTiles);
-  const uint32_t resident = maxTiles > 0 ? encodeGrid(P, floatType, tileBlocks, numTickets) : 0u;
+  const bool wideStage = encoderWideStage(floatType, tileBlocks, maxTiles);
+  const uint32_t resident = maxTiles > 0 ? encodeGrid(P, floatType, tileBlocks, numTickets, wideStage) : 0u;
   const bool hwDispatch = tileBlocks != kBlocksPerSingleTile && encoderHardwareDispatch(numTickets, resident, floatType, tileBlocks);
   uint16_t* spill = nullptr;
   uint32_t* spillFlags = nullptr;
@@ -1571,7 +1605,7 @@ int encodeCommon(
     e.outCapacity = outCapacity;
     e.useChecksum = (useChecksum && floatType) ? 1 : 0;
     e.checksum = (useChecksum && floatType) ? checksumTemp : nullptr;
-    int rc = launchEncode(P, floatType, e, tileBlocks, grid, hwDispatch, stream);
+    int rc = launchEncode(P, floatType, e, tileBlocks, grid, hwDispatch, wideStage, stream);
     if (rc) return rc;
   }
   return DGPU_OK;

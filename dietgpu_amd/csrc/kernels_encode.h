@@ -72,14 +72,20 @@ constexpr uint32_t kSpillStageWords = 1024;       // bf16 / fp32: the compressed
 // 1024 words most blocks of BASELINE config 4 flushed (encode 107 us, and the spill traffic pushed
 // the archive out of the memory-side cache: decode 122 us); 1280 words (5 workgroups per CU): 91 / 104.
 constexpr uint32_t kSpillStageWordsFp16 = 1280;
+// ... and bf16 / fp32 batches of elements of few tiles take the same 1280 words (k_ans_encode, kWide; capi.hip,
+// encoderWideStage): five workgroups per CU instead of six and no block of N(0,1) exponents -- 717 words on average,
+// the flush check fires above 768 -- ever flushes: 256 x 512 Ki bf16 encode 90.2 -> 87.5 us, fp32 step - 1.6 %; elements
+// of hundreds of tiles lose (16 x 8 Mi 112 -> 116 us: fewer tiles in flight behind the in-order commit) and keep 1024
+// (profiles/r06_ab_encoder_five_per_cu_*.txt).
+constexpr uint32_t kSpillStageWordsWide = 1280;
 constexpr uint32_t kFlushRows = 8;
 // words of spill slot per block: the worst case of a block (whole vectors)
 __host__ __device__ constexpr uint32_t encSpillSlotWords(int P) { return roundUp(encStageWords(P), 8u) + 8u; }
 
 // (Raw bytes keep the worst-case stage: a 1664-word stage with spill slots -- 4 workgroups per CU -- measured -2 %
 // for 43 MiB more temp memory, and nothing once the row stored under the ballot; docs/HISTORY.md section 5, "Config 2".)
-__host__ __device__ constexpr uint32_t encStageCap(int P, bool spill, uint32_t ft) {
-  return spill ? (ft == kFloat16 ? kSpillStageWordsFp16 : kSpillStageWords) : encStageWords(P);
+__host__ __device__ constexpr uint32_t encStageCap(int P, bool spill, uint32_t ft, bool wide = false) {
+  return spill ? (ft == kFloat16 ? kSpillStageWordsFp16 : (wide ? kSpillStageWordsWide : kSpillStageWords)) : encStageWords(P);
 }
 // Blocks per tile = per workgroup: 8 (256 threads), or 4 (128 threads) for batches whose elements have
 // at most 4 blocks -- an 8-block tile would leave half of its waves without a block there.
@@ -90,10 +96,10 @@ constexpr uint32_t kBlocksPerTinyTile = 2;
 // ... and batches of SINGLE-block elements go to k_ans_encode_pair (kernels_pairs.h): two ELEMENTS per wavefront
 constexpr uint32_t kBlocksPerSingleTile = 1;
 __host__ __device__ constexpr uint32_t encThreads(uint32_t tileBlocks) { return tileBlocks * 32u; }
-__host__ __device__ constexpr uint32_t encLdsBytes(int P, bool spill, uint32_t ft, uint32_t tileBlocks) {
+__host__ __device__ constexpr uint32_t encLdsBytes(int P, bool spill, uint32_t ft, uint32_t tileBlocks, bool wide = false) {
   return 4096u                                       // packed symbol table
       + 128u                                         // tile bookkeeping
-      + tileBlocks * encStageCap(P, spill, ft) * 2u  // bitstream stage per half-wave
+      + tileBlocks * encStageCap(P, spill, ft, wide) * 2u  // bitstream stage per half-wave
       + tileBlocks * 512u;                           // symbol ring, 16 rows per half-wave
 }
 
@@ -531,7 +537,8 @@ static_assert(encGuardLimit(9, 120) + 256u <= encStageWords(9) + kEncGuardSlackW
 // `symbol index < n`.  Three VALU more per row than the full-block step, against the scalar path's one memory round
 // trip per eight rows (bf16, 256 x 530 000: encode 120 -> 112 us, 32768 x 4000: 237 -> 138 us;
 // profiles/r05_ab_partial_blocks.txt).
-template <int P, uint32_t FT, bool kFull, bool kSpill, bool kGuard = false, bool kPool = false, bool kTail = false>
+// kWide (with kSpill): the stage holds encStageCap(P, true, FT, true) words.
+template <int P, uint32_t FT, bool kFull, bool kSpill, bool kGuard = false, bool kPool = false, bool kTail = false, bool kWide = false>
 __device__ __forceinline__ uint32_t encodeRows(
     const ChunkSource<FT>& src,
     uint32_t n,                           // symbols in this half's block (0 = idle half)
@@ -563,7 +570,7 @@ __device__ __forceinline__ uint32_t encodeRows(
     if (!kSpill) return;
     const uint32_t o0 = __builtin_amdgcn_readlane(outOff, 0);
     const uint32_t o1 = __builtin_amdgcn_readlane(outOff, 32);
-    if ((o0 > o1 ? o0 : o1) + kFlushRows * 32u <= encStageCap(P, true, FT)) return;  // wave-uniform
+    if ((o0 > o1 ? o0 : o1) + kFlushRows * 32u <= encStageCap(P, true, FT, kWide)) return;  // wave-uniform
     // whole 16-byte vectors go to the spill slot, the (< 8 word) rest moves to the front
     uint32_t nvec = outOff >> 3;
     if (spilled + nvec * 8u > encSpillSlotWords(P)) {  // (only with a table that does not cover the data)
@@ -839,12 +846,13 @@ __device__ __forceinline__ uint32_t lookBackTwoLevel(const uint64_t* desc, uint6
 // histogram that does not cover the data, see encodeRows).  The element's last tile finds the flag in its inclusive
 // prefix and reports the element as FAILED -- outSize[b] = 0, archive magic cleared -- instead of as a success with
 // a corrupt archive.  (Upstream has no such outcome: its per-block scratch is simply overrun, GpuANSEncode.cuh:355-358.)
-template <int P, uint32_t FT, bool kSpill, uint32_t kTB, bool kPersistent>
+template <int P, uint32_t FT, bool kSpill, uint32_t kTB, bool kPersistent, bool kWide = false>
 __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_ans_encode(EncodeArgs a) {
   static_assert(kTB >= 2u, "single-block elements are k_ans_encode_pair's");
+  static_assert(!kWide || (kSpill && FT != kFloat16 && kTB == kBlocksPerTile && kPersistent), "the wide stage exists for persistent 8-block bf16 / fp32 tiles");
   constexpr uint32_t kThreads = encThreads(kTB);
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  constexpr uint32_t kCap = encStageCap(P, kSpill, FT);
+  constexpr uint32_t kCap = encStageCap(P, kSpill, FT, kWide);
   // bookkeeping sits BELOW the stages so that a stage overrun (see encodeRows) can never reach it
   uint4* sTable = (uint4*)smem;
   TileShared* sh = (TileShared*)(smem + 4096);
@@ -996,7 +1004,7 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
       uint32_t spilled = 0;  // words already in the spill slot
       bool overrun = false;
       if (waveFull || waveHalf) {
-        words = encodeRows<P, FT, true, kSpill, false, kPool>(src, n, kRowsPerBlock, tableLds, stageLds, sRing + hw * 512u, hl, upper,
+        words = encodeRows<P, FT, true, kSpill, false, kPool, false, kWide>(src, n, kRowsPerBlock, tableLds, stageLds, sRing + hw * 512u, hl, upper,
                                                               spillSlot, spilled, state, overrun, &pool);
       } else {
         // rows needed by the larger of the two halves (uniform)
@@ -1006,10 +1014,10 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
           nA = size - beginA < kBlockSize ? size - beginA : kBlockSize;  // first half is never smaller than the second
         }
         if (aligned) {  // uniform: the chunked path bounded by n (kTail); else the scalar path
-          words = encodeRows<P, FT, true, kSpill, false, kPool, true>(src, n, divUp(nA, 32u), tableLds, stageLds, sRing + hw * 512u, hl,
+          words = encodeRows<P, FT, true, kSpill, false, kPool, true, kWide>(src, n, divUp(nA, 32u), tableLds, stageLds, sRing + hw * 512u, hl,
                                                                       upper, spillSlot, spilled, state, overrun, &pool);
         } else {
-          words = encodeRows<P, FT, false, kSpill, false, kPool>(src, n, divUp(nA, 32u), tableLds, stageLds, nullptr, hl, upper, spillSlot,
+          words = encodeRows<P, FT, false, kSpill, false, kPool, false, kWide>(src, n, divUp(nA, 32u), tableLds, stageLds, nullptr, hl, upper, spillSlot,
                                                                  spilled, state, overrun, &pool);
         }
       }
