@@ -1437,7 +1437,7 @@ int encodeCommon(
   DGPU_ALLOC(tileDesc, uint64_t, arena, lists ? std::max<size_t>(numListedTiles, 1u) : (size_t)B * std::max(maxTiles, 1u));
   DGPU_ALLOC(claims, uint32_t, arena, lists ? std::max<size_t>(numListedTiles, 1u) : (size_t)B * std::max(maxTiles, 1u));
   // second level of the look-back for elements of more than 64 tiles (kernels_encode.h, lookBackTwoLevel): rectangles only
-  const uint32_t lookbackGroups = (!lists && tileBlocks != kBlocksPerSingleTile && maxTiles > kLookbackGroup && g_twoLevelLookback.load() != 0)
+  const uint32_t lookbackGroups = (floatType != 0 && !lists && tileBlocks != kBlocksPerSingleTile && maxTiles > kLookbackGroup && g_twoLevelLookback.load() != 0)
       ? divUp(maxTiles, kLookbackGroup) : 0u;
   uint64_t* groupWords = nullptr;
   if (lookbackGroups) {
@@ -1598,6 +1598,11 @@ int encodeCommon(
     e.groupWords = groupWords;
     e.groupsPerElement = lookbackGroups;
     e.absentModulo = absentWorkgroupModulo();
+    {
+      // tiles of ONE element that are in flight at once: the resident workgroups over the elements of this launch
+      const uint32_t elems = lists ? std::max(1u, numTickets / std::max(maxTiles, 1u)) : std::max(numElems, 1u);
+      e.pollLong = std::min(maxTiles, std::max(resident, 1u) / elems) > 12u ? 1u : 0u;
+    }
     e.spill = spill;
     e.spillFlags = spillFlags;
     e.spillPairs = spillPairs;

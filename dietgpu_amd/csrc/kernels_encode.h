@@ -109,8 +109,8 @@ constexpr uint64_t kDescAggregate = 1ull << 62;
 constexpr uint64_t kDescInclusive = 2ull << 62;
 constexpr uint64_t kDescValueMask = (1ull << 62) - 1;
 constexpr uint64_t kDescFailed = 1ull << 40;  // sticky: a tile overran its stage (see k_ans_encode)
-// pause between two polls of an unpublished descriptor: 512 cycles, doubling up to 16 x 512 (see lookBackExclusive)
-constexpr uint32_t kLookbackPollPauseMax = 16;
+// pause between two polls of an unpublished descriptor: 64 cycles, doubling up to 128 x 64 = 3.4 us (see lookBackExclusive)
+constexpr uint32_t kLookbackPollPauseMax = 128;
 
 struct EncodeArgs {
   BatchView in;              // raw bytes (FT == 0) or float words (FT != 0); size(b) = symbols = bytes / words
@@ -127,6 +127,7 @@ struct EncodeArgs {
   uint64_t* groupWords;      // [B] x {[groupsPerElement] x kGroupArriveStride arrival words, [groupsPerElement] descriptors}
   uint32_t groupsPerElement;
   uint32_t absentModulo;     // test hook: workgroups with index % absentModulo == 1 start ~0.5 ms late (0 = off)
+  uint32_t pollLong;         // look-back: pause at the maximum from the first poll (many tiles of an element in flight at once: long waits)
   uint16_t* spill;           // kSpill kernels only.  Persistent grids (k_ans_encode, 8-block float tiles): [gridDim.x][blocks
                              // per tile][encSpillSlotWords(P)], a workgroup's slots are its own.  Hardware-dispatched grids
                              // (k_ans_encode with 2- / 4-block float tiles, k_ans_encode_pair): [spillPairs][2]
@@ -721,18 +722,23 @@ __device__ __forceinline__ uint32_t encodeRows(
 // aggregates down to the nearest inclusive prefix and returns the tile's exclusive prefix (u16 words); `failed` picks up
 // the sticky failure flag of every descriptor counted.  64 * kLookbackPerLane predecessors per round trip (lane l holds
 // the kLookbackPerLane nearest ones beyond those of lanes < l).  A descriptor that has not been published is polled with
-// LONG pauses between the polls (doubling from 0.2 us to 3.4 us: a short wait stays short): the descriptors of the ~1500
+// LONG pauses between the polls (doubling from 30 ns to 3.4 us: a short wait stays short): the descriptors of the ~1500
 // tiles in flight share a few dozen cache lines, every poll is an L2-bypassing load of such a line and every publication a
 // write-through store to one, and with short pauses the polls of the waiting tiles are what the publications queue
 // behind (measured on MI355X, bf16, fixed pauses,
 // profiles/r06_ab_lookback_backoff_*.txt: 1 x 128 Mi encode 115.1 us with s_sleep 1, 113.3 / 110.3 / 106.0 with 8 / 32 /
 // 127; 16 x 8 Mi 122.0 -> 113.4; and reading 256 or 512 descriptors per round trip instead of 64 -- 4 or 8 times the
 // lines per poll -- costs 25-40 us, profiles/r06_ab_lookback_window_*.txt).
-// `longChains`: the element has more than 16 tiles -- dozens to ~1500 tiles of one element in flight, long waits:
-// the pause starts at its maximum (1 x 128 Mi encode 112.5 -> 105.8 us against the doubling pause, 16 x 8 Mi 119.9 ->
-// 113.1; on 256 x 512 Ki, 16 tiles per element, the doubling pause is the better one by 1 %: profiles/r06_ab_poll_pause_*.txt).
+// `longChains` (EncodeArgs::pollLong: more than a dozen tiles of an element in flight at once -- few large elements,
+// long waits): the pause starts at its maximum (1 x 128 Mi encode 112.5 -> 105.8 us against the doubling pause, 16 x 8 Mi
+// 119.9 -> 113.1, 64 x 2 Mi 93.2 -> 91.6).  Batches of many elements -- a handful of an element's tiles in flight, short
+// waits -- keep the doubling pause: 256 x 512 Ki bf16 is 1 % faster with it, and 256 x 1 MiB Zipf bytes lose 4 us of 144 to
+// the long one (profiles/r06_ab_poll_pause_*.txt, r06_ab_round6_vs_round5_u8.txt).
 // `endedAtStart` (nullable): set when the walk went all the way down to index 0 without meeting a real inclusive
 // prefix -- what the caller then holds is the sum of `desc[0 .. tile)` (the second level of lookBackTwoLevel needs to know).
+// (kTrackStart = false compiles to the plain walk: the raw-byte encoder, whose row loop the compiler schedules 3 % worse
+// with the tracking in the same kernel, never asks -- profiles/r06_ab_raw_encoder_regression_u8.txt)
+template <bool kTrackStart = false>
 __device__ __forceinline__ uint32_t lookBackExclusive(const uint64_t* desc, uint32_t tile, uint32_t lane, bool& failed, bool longChains,
                                                       bool* endedAtStart = nullptr) {
   uint32_t exclusive = 0;
@@ -752,16 +758,16 @@ __device__ __forceinline__ uint32_t lookBackExclusive(const uint64_t* desc, uint
     for (int j = 0; j < (int)kLookbackPerLane; ++j) {
       if (sawIncl) continue;  // (beyond the lane's first inclusive prefix nothing counts)
       const int idx = base - (int)(lane * kLookbackPerLane) - j;
-      uint32_t pause = longChains ? kLookbackPollPauseMax : 1u;  // in units of s_sleep(8) = 512 cycles: 1, 2, 4, ... kLookbackPollPauseMax
+      uint32_t pause = longChains ? kLookbackPollPauseMax : 1u;  // in units of s_sleep(1) = 64 cycles: 1, 2, 4, ... kLookbackPollPauseMax
       while ((d[j] >> 62) == 0) {
-        for (uint32_t q = 0; q < pause; ++q) __builtin_amdgcn_s_sleep(8);
+        for (uint32_t q = 0; q < pause; ++q) __builtin_amdgcn_s_sleep(1);
         pause = pause * 2u < kLookbackPollPauseMax ? pause * 2u : kLookbackPollPauseMax;
         d[j] = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       sum += (uint32_t)d[j];
       sawFailed = sawFailed || (d[j] & kDescFailed) != 0ull;
       sawIncl = (d[j] >> 62) == 2;
-      inclIsVirtual = idx < 0;
+      if (kTrackStart) inclIsVirtual = idx < 0;
     }
     const uint64_t inclMask = __ballot(sawIncl);
     const int firstIncl = inclMask ? (__ffsll((unsigned long long)inclMask) - 1) : 64;
@@ -769,12 +775,12 @@ __device__ __forceinline__ uint32_t lookBackExclusive(const uint64_t* desc, uint
     exclusive += waveReduceSum(counted ? sum : 0u);
     failed = failed || __ballot(counted && sawFailed) != 0ull;
     if (firstIncl < 64) {
-      virtualEnd = ((__ballot(sawIncl && inclIsVirtual) >> firstIncl) & 1ull) != 0ull;
+      if (kTrackStart) virtualEnd = ((__ballot(sawIncl && inclIsVirtual) >> firstIncl) & 1ull) != 0ull;
       break;
     }
     base -= 64 * (int)kLookbackPerLane;
   }
-  if (endedAtStart) *endedAtStart = virtualEnd;
+  if (kTrackStart && endedAtStart) *endedAtStart = virtualEnd;
   return exclusive;
 }
 
@@ -789,7 +795,7 @@ __device__ __forceinline__ uint32_t lookBackExclusive(const uint64_t* desc, uint
 constexpr uint32_t kLookbackGroup = 64;
 constexpr uint32_t kGroupArriveStride = 16;  // u64 words between two groups' arrival words (a 128-byte line each)
 __device__ __forceinline__ uint32_t lookBackTwoLevel(const uint64_t* desc, uint64_t* groupArrive, uint64_t* groupDesc, uint32_t tile,
-                                                     uint32_t numTiles, uint32_t aggregate, uint32_t lane, bool& failed) {
+                                                     uint32_t numTiles, uint32_t aggregate, uint32_t lane, bool& failed, bool longChains) {
   const uint32_t g = tile / kLookbackGroup, l = tile % kLookbackGroup;
   const uint32_t groupTiles = (g + 1u) * kLookbackGroup <= numTiles ? kLookbackGroup : numTiles - g * kLookbackGroup;
   if (lane == 0) {
@@ -805,8 +811,8 @@ __device__ __forceinline__ uint32_t lookBackTwoLevel(const uint64_t* desc, uint6
     }
   }
   bool atGroupStart = false;
-  uint32_t exclusive = lookBackExclusive(desc + (size_t)g * kLookbackGroup, l, lane, failed, true, &atGroupStart);
-  if (atGroupStart && g > 0u) exclusive += lookBackExclusive(groupDesc, g, lane, failed, true);
+  uint32_t exclusive = lookBackExclusive<true>(desc + (size_t)g * kLookbackGroup, l, lane, failed, longChains, &atGroupStart);
+  if (atGroupStart && g > 0u) exclusive += lookBackExclusive(groupDesc, g, lane, failed, longChains);
   return exclusive;
 }
 
@@ -1050,11 +1056,37 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
         }
 
         bool failed = tileFailed;
-        const bool twoLevel = a.groupWords != nullptr && numTiles > kLookbackGroup;  // (uniform)
-        uint64_t* groupArrive = twoLevel ? a.groupWords + (size_t)b * a.groupsPerElement * (kGroupArriveStride + 1u) : nullptr;
-        uint64_t* groupDesc = twoLevel ? groupArrive + (size_t)a.groupsPerElement * kGroupArriveStride : nullptr;
-        const uint32_t exclusive = twoLevel ? lookBackTwoLevel(desc, groupArrive, groupDesc, tile, numTiles, aggregate, lane, failed)
-                                            : lookBackExclusive(desc, tile, lane, failed, numTiles > 16u);
+        // (two levels for floats only: raw-byte elements of more than 64 tiles walk the one level, see lookBackExclusive)
+        const bool twoLevel = FT != 0u && a.groupWords != nullptr && numTiles > kLookbackGroup;  // (uniform)
+        uint64_t* groupDesc = nullptr;
+        uint32_t exclusive;
+        if constexpr (FT != 0u) {
+          uint64_t* groupArrive = twoLevel ? a.groupWords + (size_t)b * a.groupsPerElement * (kGroupArriveStride + 1u) : nullptr;
+          groupDesc = twoLevel ? groupArrive + (size_t)a.groupsPerElement * kGroupArriveStride : nullptr;
+          exclusive = twoLevel ? lookBackTwoLevel(desc, groupArrive, groupDesc, tile, numTiles, aggregate, lane, failed, a.pollLong != 0u)
+                               : lookBackExclusive(desc, tile, lane, failed, a.pollLong != 0u);
+        } else {
+          // raw bytes: the walk written out in place, one level, short pauses (as rounds 1-5 had it)
+          exclusive = 0;
+          int base = (int)tile - 1;
+          while (base >= 0) {
+            const int idx = base - (int)lane;
+            uint64_t d = kDescInclusive;  // virtual tile -1: inclusive prefix 0
+            if (idx >= 0) {
+              do {
+                d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((d >> 62) == 0) __builtin_amdgcn_s_sleep(1);
+              } while ((d >> 62) == 0);
+            }
+            const uint64_t inclMask = __ballot((d >> 62) == 2);
+            const int firstIncl = inclMask ? (__ffsll((unsigned long long)inclMask) - 1) : 64;
+            const bool counted = (int)lane <= firstIncl;
+            exclusive += waveReduceSum(counted ? (uint32_t)d : 0u);
+            failed = failed || __ballot(counted && (d & kDescFailed) != 0ull) != 0ull;
+            if (firstIncl < 64) break;
+            base -= 64;
+          }
+        }
 
         const uint32_t inclusive = exclusive + aggregate;
         if (lane == 0) {
