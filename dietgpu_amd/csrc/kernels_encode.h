@@ -1056,18 +1056,14 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
         }
 
         bool failed = tileFailed;
-        // (two levels for floats only: raw-byte elements of more than 64 tiles walk the one level, see lookBackExclusive)
+        // Few tiles of an element in flight (a.pollLong == 0: short waits): the walk written out in place with short
+        // pauses, as rounds 1-5 had it -- as a function with its pause bookkeeping it cost the raw-byte encoder 3 us of
+        // 144 (profiles/r06_ab_raw_encoder_regression_u8.txt).  Many in flight: long pauses, and two levels for float
+        // elements of more than 64 tiles (lookBackExclusive, lookBackTwoLevel).
         const bool twoLevel = FT != 0u && a.groupWords != nullptr && numTiles > kLookbackGroup;  // (uniform)
         uint64_t* groupDesc = nullptr;
-        uint32_t exclusive;
-        if constexpr (FT != 0u) {
-          uint64_t* groupArrive = twoLevel ? a.groupWords + (size_t)b * a.groupsPerElement * (kGroupArriveStride + 1u) : nullptr;
-          groupDesc = twoLevel ? groupArrive + (size_t)a.groupsPerElement * kGroupArriveStride : nullptr;
-          exclusive = twoLevel ? lookBackTwoLevel(desc, groupArrive, groupDesc, tile, numTiles, aggregate, lane, failed, a.pollLong != 0u)
-                               : lookBackExclusive(desc, tile, lane, failed, a.pollLong != 0u);
-        } else {
-          // raw bytes: the walk written out in place, one level, short pauses (as rounds 1-5 had it)
-          exclusive = 0;
+        uint32_t exclusive = 0;
+        if (a.pollLong == 0u && !twoLevel) {
           int base = (int)tile - 1;
           while (base >= 0) {
             const int idx = base - (int)lane;
@@ -1086,6 +1082,13 @@ __global__ __launch_bounds__(encThreads(kTB)) __attribute__((amdgpu_waves_per_eu
             if (firstIncl < 64) break;
             base -= 64;
           }
+        } else if constexpr (FT != 0u) {
+          uint64_t* groupArrive = twoLevel ? a.groupWords + (size_t)b * a.groupsPerElement * (kGroupArriveStride + 1u) : nullptr;
+          groupDesc = twoLevel ? groupArrive + (size_t)a.groupsPerElement * kGroupArriveStride : nullptr;
+          exclusive = twoLevel ? lookBackTwoLevel(desc, groupArrive, groupDesc, tile, numTiles, aggregate, lane, failed, a.pollLong != 0u)
+                               : lookBackExclusive(desc, tile, lane, failed, true);
+        } else {
+          exclusive = lookBackExclusive(desc, tile, lane, failed, true);
         }
 
         const uint32_t inclusive = exclusive + aggregate;
