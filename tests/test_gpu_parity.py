@@ -988,6 +988,48 @@ def test_lookback_windows_bf16_40m(dg, absent):
     assert torch.equal(out.view(torch.int16), t.view(torch.int16))
 
 
+@pytest.mark.parametrize("absent", [0, 3])
+@pytest.mark.parametrize("ft", [O.BFLOAT16, O.FLOAT32])
+def test_two_level_lookback_of_several_elements(dg, ft, absent):
+    # Float elements of more than 64 tiles walk the look-back in two levels (groups of 64 tiles: an arrival word and a
+    # descriptor per group, kernels_encode.h lookBackTwoLevel).  Three elements of 130 tiles each -- two whole groups and a
+    # group of two, the last tile of a group not the last of its element and the other way round -- and, beside them in
+    # the same rectangle, one of 64 tiles (one level) and one of 65 (a group of one); with late workgroups the group's
+    # last tile can publish the inclusive prefix before the group's arrivals are complete.
+    tile = 8 * 4096
+    ns = [130 * tile, 130 * tile - 5000, 64 * tile, 130 * tile, 65 * tile - 17]
+    rng = np.random.default_rng(640 + ft + absent)
+    ws = []
+    for i, n in enumerate(ns):
+        if i == 3:  # incompressible: every block spills, aggregates near their maximum
+            dt = np.uint32 if ft == O.FLOAT32 else np.uint16
+            ws.append(rng.integers(0, 1 << (8 * dt().itemsize), n, dtype=np.uint64).astype(dt))
+        else:
+            ws.append(np.ascontiguousarray(np.roll(refgen.generate_floats(ft, n), 31 * i)))
+    ts = [words_to_tensor(ft, w) for w in ws]
+    L = dg.lib()
+    L.dgpu_debug_set_work_lists(0)  # (the rectangle: the two levels exist there)
+    L.dgpu_debug_set_absent_workgroups(absent)
+    try:
+        comp, sizes, _ = dg.compress_data(True, ts, True)
+    finally:
+        L.dgpu_debug_set_absent_workgroups(0)
+        L.dgpu_debug_set_work_lists(-1)
+    hs = sizes.cpu().numpy()
+    rows = []
+    for i, w in enumerate(ws):
+        want = O.float_compress(ft, w, 10, use_checksum=True)
+        assert hs[i] == want.size, (i, hs[i], want.size)
+        got = comp[i, : want.size].cpu().numpy()
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (i, bad[:4], want.size)
+        rows.append(comp[i, : want.size].clone())
+    outs = [torch.empty_like(t) for t in ts]
+    status = torch.zeros((len(ts),), dtype=torch.uint8, device=DEV)
+    dg.decompress_data(True, rows, outs, True, None, status)
+    assert status.cpu().numpy().all() and all((tensor_to_words(ft, o) == w).all() for o, w in zip(outs, ws))
+
+
 # ------------------------------------------------------------ malformed archives
 def _decode_status(dg, as_float, arch_np, out_like, prob_bits=10):
     arch = torch.from_numpy(arch_np.copy()).to(DEV)
